@@ -1,0 +1,230 @@
+"""Test-side helpers: ctypes bindings for the CPU oracle (oracle/liblc3_oracle*.so), the compiled
+ETSI reference (oracle/_ref/liblc3_etsi_fl.so, optional) and the deterministic synthetic PCM generator
+(SURVEY.md 8(d) "Synthetic PCM").  TEST INFRASTRUCTURE ONLY -- the product never imports this."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+REF_SO = os.path.join(ORACLE_DIR, "_ref", "liblc3_etsi_fl.so")
+
+
+def build_oracle():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR, "restatement"])
+
+
+def have_ref():
+    return os.path.exists(REF_SO)
+
+
+# ---------------------------------------------------------------------------------------------
+# synthetic PCM (int16): sinusoids + coloured noise + transients; some silent / full-scale streams
+# ---------------------------------------------------------------------------------------------
+def synth_pcm(n_streams, n_frames, frame_len, fs, seed=1, dtype=np.int16):
+    """[n_streams, n_frames, frame_len] deterministic int16 test signal."""
+    out = np.zeros((n_streams, n_frames * frame_len), dtype=np.float64)
+    t = np.arange(n_frames * frame_len) / fs
+    for s in range(n_streams):
+        rng = np.random.RandomState((0x9E3779B9 * (s + 1) + seed) & 0x7FFFFFFF)
+        kind = s % 64
+        if kind == 63:            # digital silence
+            continue
+        if kind == 62:            # full-scale white noise
+            out[s] = rng.uniform(-32768, 32767, size=t.size)
+            continue
+        x = np.zeros_like(t)
+        for _ in range(3):
+            f = rng.uniform(80.0, 0.4 * fs)
+            a = rng.uniform(0.02, 0.25) * 32767
+            x += a * np.sin(2 * np.pi * f * t + rng.uniform(0, 2 * np.pi))
+        if kind % 4 == 1:         # strongly periodic (pitch) stream to exercise LTPF
+            f0 = rng.uniform(90.0, 380.0)
+            for h in range(1, 12):
+                x += (0.12 / h) * 32767 * np.sin(2 * np.pi * f0 * h * t + h)
+        noise = rng.standard_normal(t.size)
+        noise = np.convolve(noise, [0.5, 0.3, 0.15, 0.05], mode="same")   # pink-ish
+        x += noise * 32767 * 10 ** (-30 / 20)
+        # 20 dB step transient every 37 frames
+        env = np.ones_like(t)
+        for k in range(0, n_frames, 37):
+            a0 = k * frame_len + frame_len // 3
+            env[a0:a0 + frame_len // 2] *= 10.0
+        x *= env * 0.1
+        out[s] = x
+    out = np.clip(np.rint(out), -32768, 32767)
+    return out.reshape(n_streams, n_frames, frame_len).astype(dtype)
+
+
+# ---------------------------------------------------------------------------------------------
+# oracle restatement
+# ---------------------------------------------------------------------------------------------
+class Trace(C.Structure):
+    _fields_ = [
+        ("spec_mdct", C.c_float * 960), ("s12k8", C.c_float * 129), ("T0", C.c_int), ("normcorr", C.c_float),
+        ("ltpf_param", C.c_int * 3), ("ltpf_bits", C.c_int), ("attack", C.c_int), ("ener", C.c_float * 64),
+        ("bw_idx", C.c_int), ("scf", C.c_float * 16), ("scf_idx", C.c_int * 7), ("scf_q", C.c_float * 16),
+        ("spec_shaped", C.c_float * 960), ("tns_nfilt", C.c_int), ("tns_order", C.c_int * 2),
+        ("tns_rc_idx", C.c_int * 16), ("tns_bits", C.c_int), ("spec_tns", C.c_float * 960),
+        ("target_bits_quant", C.c_int), ("gain0", C.c_float), ("gg_idx0", C.c_int), ("gg_min", C.c_int),
+        ("nbits0", C.c_int), ("gain", C.c_float), ("gg_idx", C.c_int), ("gain_change", C.c_int),
+        ("nbits", C.c_int), ("nbits2", C.c_int), ("lastnz", C.c_int), ("lsb_mode", C.c_int),
+        ("xq", C.c_int * 960), ("fac_ns", C.c_int), ("n_res_bits", C.c_int), ("bp_side", C.c_int),
+        ("mask_side", C.c_int),
+    ]
+
+
+class Oracle:
+    """One multi-channel encoder instance of the CPU restatement."""
+
+    def __init__(self, fs, channels=1, frame_ms=10.0, hrmode=0, bitrate=64000, portable_math=False, bandwidth=0):
+        name = "liblc3_oracle_pm.so" if portable_math else "liblc3_oracle.so"
+        path = os.path.join(ORACLE_DIR, name)
+        if not os.path.exists(path):
+            build_oracle()
+        self.lib = C.CDLL(path)
+        L = self.lib
+        L.lc3o_enc_set_frame_ms.argtypes = [C.c_void_p, C.c_float]
+        L.lc3o_enc_frame.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.POINTER(C.c_int)]
+        for f in ("lc3o_enc_init", "lc3o_enc_set_hrmode", "lc3o_enc_set_bitrate", "lc3o_enc_set_bandwidth",
+                  "lc3o_enc_get_input_samples", "lc3o_enc_get_num_bytes", "lc3o_enc_get_real_bitrate", "lc3o_enc_get_delay"):
+            getattr(L, f).restype = C.c_int
+        self.buf = C.create_string_buffer(L.lc3o_enc_sizeof())
+        self.p = C.cast(self.buf, C.c_void_p)
+        self.channels = channels
+        self.err = L.lc3o_enc_init(self.p, fs, channels)
+        if not self.err: self.err = L.lc3o_enc_set_frame_ms(self.p, frame_ms)
+        if not self.err: self.err = L.lc3o_enc_set_hrmode(self.p, hrmode)
+        if not self.err: self.err = L.lc3o_enc_set_bitrate(self.p, bitrate)
+        if not self.err and bandwidth: self.err = L.lc3o_enc_set_bandwidth(self.p, bandwidth)
+        if self.err:
+            raise RuntimeError("oracle setup error %d" % self.err)
+        self.N = L.lc3o_enc_get_input_samples(self.p)
+        self.nbytes = L.lc3o_enc_get_num_bytes(self.p)
+        self.trace = None
+
+    def enable_trace(self):
+        self.trace = (Trace * self.channels)()
+        self.lib.lc3o_enc_set_trace.argtypes = [C.c_void_p, C.c_void_p]
+        self.lib.lc3o_enc_set_trace(self.p, C.cast(self.trace, C.c_void_p))
+        return self.trace
+
+    def set_bitrate(self, br):
+        return self.lib.lc3o_enc_set_bitrate(self.p, br)
+
+    def encode(self, planar, bitdepth=16):
+        """planar: [channels, N] int16 (bitdepth 16) or int32."""
+        planar = np.ascontiguousarray(planar)
+        ptrs = (C.c_void_p * self.channels)(*[planar[c].ctypes.data for c in range(self.channels)])
+        out = np.zeros(self.nbytes, dtype=np.uint8)
+        nb = C.c_int(0)
+        rc = self.lib.lc3o_enc_frame(self.p, ptrs, bitdepth, out.ctypes.data, C.byref(nb))
+        if rc:
+            raise RuntimeError("oracle encode error %d" % rc)
+        assert nb.value == self.nbytes
+        return out
+
+
+def oracle_encode_streams(pcm, fs, frame_ms, hrmode, bitrates, portable_math=False):
+    """pcm [B,T,N] int16 mono streams -> list of [T, nbytes_b] uint8 arrays."""
+    B, T, N = pcm.shape
+    outs = []
+    for b in range(B):
+        o = Oracle(fs, 1, frame_ms, hrmode, int(bitrates[b]), portable_math)
+        assert o.N == N
+        frames = np.zeros((T, o.nbytes), dtype=np.uint8)
+        for t in range(T):
+            frames[t] = o.encode(pcm[b, t][None, :])
+        outs.append(frames)
+    return outs
+
+
+# ---------------------------------------------------------------------------------------------
+# compiled ETSI reference (only where oracle/_ref was built)
+# ---------------------------------------------------------------------------------------------
+class Ref:
+    def __init__(self, fs, channels=1, frame_ms=10.0, hrmode=0, bitrate=64000, bandwidth=0):
+        L = self.lib = C.CDLL(REF_SO)
+        L.lc3_enc_set_frame_ms.argtypes = [C.c_void_p, C.c_float]
+        L.lc3_enc_fl.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.POINTER(C.c_int)]
+        size = L.lc3_enc_get_size(fs, channels)
+        if size <= 0:
+            raise RuntimeError("ref: unsupported fs/channels")
+        self.buf = C.create_string_buffer(size + 8)
+        self.p = C.cast(self.buf, C.c_void_p)
+        self.channels = channels
+        err = L.lc3_enc_init(self.p, fs, channels)
+        if not err: err = L.lc3_enc_set_frame_ms(self.p, frame_ms)
+        if not err: err = L.lc3_enc_set_hrmode(self.p, hrmode)
+        if not err: err = L.lc3_enc_set_bitrate(self.p, bitrate)
+        if not err and bandwidth: err = L.lc3_enc_set_bandwidth(self.p, bandwidth)
+        self.err = err
+        if err:
+            raise RuntimeError("ref setup error %d" % err)
+        self.N = L.lc3_enc_get_input_samples(self.p)
+        self.nbytes = L.lc3_enc_get_num_bytes(self.p)
+
+    def set_bitrate(self, br):
+        return self.lib.lc3_enc_set_bitrate(self.p, br)
+
+    def encode(self, planar, bitdepth=16):
+        planar = np.ascontiguousarray(planar)
+        ptrs = (C.c_void_p * self.channels)(*[planar[c].ctypes.data for c in range(self.channels)])
+        out = np.zeros(self.nbytes, dtype=np.uint8)
+        nb = C.c_int(self.nbytes)
+        rc = self.lib.lc3_enc_fl(self.p, ptrs, bitdepth, out.ctypes.data, C.byref(nb))
+        if rc:
+            raise RuntimeError("ref encode error %d" % rc)
+        return out
+
+    def __del__(self):
+        try:
+            self.lib.lc3_free_encoder_structs(self.p)
+        except Exception:
+            pass
+
+
+def ref_encode_streams(pcm, fs, frame_ms, hrmode, bitrates):
+    B, T, N = pcm.shape
+    outs = []
+    for b in range(B):
+        o = Ref(fs, 1, frame_ms, hrmode, int(bitrates[b]))
+        assert o.N == N
+        frames = np.zeros((T, o.nbytes), dtype=np.uint8)
+        for t in range(T):
+            frames[t] = o.encode(pcm[b, t][None, :])
+        outs.append(frames)
+    return outs
+
+
+class RefDecoder:
+    """ETSI float decoder (tool use only: turns bitstreams back into PCM for distance metrics)."""
+
+    def __init__(self, fs, channels=1, frame_ms=10.0, hrmode=0):
+        L = self.lib = C.CDLL(REF_SO)
+        L.lc3_dec_set_frame_ms.argtypes = [C.c_void_p, C.c_float]
+        size = L.lc3_dec_get_size(fs, channels, 0)
+        self.buf = C.create_string_buffer(size + 8)
+        self.p = C.cast(self.buf, C.c_void_p)
+        self.channels = channels
+        err = L.lc3_dec_init(self.p, fs, channels, 0)
+        if not err: err = L.lc3_dec_set_frame_ms(self.p, frame_ms)
+        if not err: err = L.lc3_dec_set_hrmode(self.p, hrmode)
+        if err:
+            raise RuntimeError("ref decoder setup error %d" % err)
+        self.N = L.lc3_dec_get_output_samples(self.p)
+        L.lc3_dec16.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int]
+
+    def decode(self, frame_bytes):
+        frame_bytes = np.ascontiguousarray(frame_bytes, dtype=np.uint8)
+        out = np.zeros((self.channels, self.N), dtype=np.int16)
+        ptrs = (C.c_void_p * self.channels)(*[out[c].ctypes.data for c in range(self.channels)])
+        rc = self.lib.lc3_dec16(self.p, frame_bytes.ctypes.data, int(frame_bytes.size), ptrs, 0)
+        return rc, out
+
+    def __del__(self):
+        try:
+            self.lib.lc3_free_decoder_structs(self.p)
+        except Exception:
+            pass

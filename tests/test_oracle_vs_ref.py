@@ -1,0 +1,64 @@
+"""CPU, build container only: the oracle restatement against the live compiled ETSI reference (oracle/_ref).
+Skipped where oracle/_ref is absent; the committed golden vectors cover that case."""
+import numpy as np
+import pytest
+from lc3_harness import Oracle, Ref, have_ref, oracle_encode_streams, ref_encode_streams, synth_pcm
+
+pytestmark = pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built (needs /root/reference)")
+
+RATES = [16000, 24000, 32000, 48000, 64000, 80000, 96000, 128000, 160000, 192000, 256000, 320000]
+
+
+@pytest.mark.parametrize("streams", [list(range(12)), [1 + 4 * i for i in range(12)], [62, 63, 126, 127] * 3])
+def test_48k_10ms_all_rates(streams):
+    pcm = synth_pcm(max(streams) + 1, 40, 480, 48000, seed=7)[streams]
+    ref = ref_encode_streams(pcm, 48000, 10.0, 0, RATES)
+    orc = oracle_encode_streams(pcm, 48000, 10.0, 0, RATES)
+    for r, o in zip(ref, orc):
+        assert (r == o).all()
+
+
+def test_96k_2p5ms_hr():
+    rates = [256000, 198400, 320000, 672000, 256000, 256000]
+    streams = [0, 1, 2, 3, 62, 63]
+    pcm = synth_pcm(64, 80, 240, 96000, seed=3)[streams]
+    for r, o in zip(ref_encode_streams(pcm, 96000, 2.5, 1, rates), oracle_encode_streams(pcm, 96000, 2.5, 1, rates)):
+        assert (r == o).all()
+
+
+def test_stereo_bitrate_switch_bandwidth_bitdepth():
+    pcm = synth_pcm(4, 40, 480, 48000, seed=5)
+    r, o = Ref(48000, 2, 10.0, 0, 128000), Oracle(48000, 2, 10.0, 0, 128000)
+    for t in range(40):
+        assert (r.encode(pcm[0:2, t]) == o.encode(pcm[0:2, t])).all()
+        if t == 20:
+            assert r.set_bitrate(192000) == 0 and o.set_bitrate(192000) == 0
+            o.nbytes = r.nbytes = 240
+    r, o = Ref(48000, 1, 10.0, 0, 64000, bandwidth=8000), Oracle(48000, 1, 10.0, 0, 64000, bandwidth=8000)
+    for t in range(40):
+        assert (r.encode(pcm[2:3, t]) == o.encode(pcm[2:3, t])).all()
+    for depth, scale in ((24, 200), (32, 60000)):
+        r, o = Ref(48000, 1, 10.0, 0, 96000), Oracle(48000, 1, 10.0, 0, 96000)
+        p32 = pcm[3].astype(np.int32) * scale + 77
+        for t in range(40):
+            assert (r.encode(p32[t][None], depth) == o.encode(p32[t][None], depth)).all()
+
+
+def test_api_error_codes_match():
+    import ctypes as C
+    from lc3_harness import REF_SO
+    L = C.CDLL(REF_SO)
+    L.lc3_enc_set_frame_ms.argtypes = [C.c_void_p, C.c_float]
+    for fs, ms, hr, br in [(48000, 10.0, 0, 8000), (48000, 10.0, 0, 400000), (48000, 7.5, 0, 64000), (32000, 10.0, 1, 64000),
+                           (96000, 10.0, 0, 256000), (96000, 2.5, 1, 100000), (48000, 5.0, 1, 148800), (44100, 10.0, 0, 64000)]:
+        buf = C.create_string_buffer(L.lc3_enc_get_size(fs, 1) + 8)
+        p = C.cast(buf, C.c_void_p)
+        want = [L.lc3_enc_init(p, fs, 1), L.lc3_enc_set_frame_ms(p, ms), L.lc3_enc_set_hrmode(p, hr), L.lc3_enc_set_bitrate(p, br),
+                L.lc3_enc_get_num_bytes(p), L.lc3_enc_get_input_samples(p), L.lc3_enc_get_delay(p)]
+        L.lc3_free_encoder_structs(p)
+        o = C.CDLL(Oracle.__init__.__globals__["os"].path.join(Oracle.__init__.__globals__["ORACLE_DIR"], "liblc3_oracle.so"))
+        o.lc3o_enc_set_frame_ms.argtypes = [C.c_void_p, C.c_float]
+        ob = C.create_string_buffer(o.lc3o_enc_sizeof()); q = C.cast(ob, C.c_void_p)
+        got = [o.lc3o_enc_init(q, fs, 1), o.lc3o_enc_set_frame_ms(q, ms), o.lc3o_enc_set_hrmode(q, hr), o.lc3o_enc_set_bitrate(q, br),
+               o.lc3o_enc_get_num_bytes(q), o.lc3o_enc_get_input_samples(q), o.lc3o_enc_get_delay(q)]
+        assert got == want, (fs, ms, hr, br, got, want)
