@@ -1,0 +1,171 @@
+"""ctypes binding of the C-ABI library (include/lc3.h, include/lc3plus_batch.h).
+
+Nothing here computes anything: every call goes to liblc3plus_hip.so.  If the library has not been built the
+import of a symbol fails loudly -- there is no Python or CPU fallback path."""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+# every symbol include/lc3.h and include/lc3plus_batch.h declare
+EXPORTS = [
+    "lc3_version", "lc3_channels_supported", "lc3_samplerate_supported", "lc3_enc_get_size", "lc3_enc_init",
+    "lc3_enc_set_frame_ms", "lc3_enc_set_hrmode", "lc3_enc_set_bitrate", "lc3_enc_set_bandwidth",
+    "lc3_enc_get_input_samples", "lc3_enc_get_num_bytes", "lc3_enc_get_real_bitrate", "lc3_enc_get_delay",
+    "lc3_enc_fl", "lc3_enc16", "lc3_enc24", "lc3_enc32", "lc3_enc_free_memory", "lc3_free_encoder_structs",
+    "lc3plus_enc_batch_create", "lc3plus_enc_batch_destroy", "lc3plus_enc_batch_input_samples",
+    "lc3plus_enc_batch_num_bytes", "lc3plus_enc_batch_stride", "lc3plus_enc_batch_set_bitrate",
+    "lc3plus_enc_batch_set_bandwidth", "lc3plus_enc_batch_encode", "lc3plus_enc_batch_last_kernel_ms",
+    "lc3plus_enc_init", "lc3plus_enc_set_frame_ms", "lc3plus_enc_set_hrmode", "lc3plus_enc_set_bitrate",
+    "lc3plus_enc16", "lc3plus_enc_get_size",
+]
+
+
+class LC3Error(RuntimeError):
+    def __init__(self, code, what=""):
+        super().__init__("LC3_Error %d %s" % (code, what))
+        self.code = code
+
+
+def lib_path():
+    return os.path.join(HERE, "liblc3plus_hip.so")
+
+
+def load_library():
+    global _LIB
+    if _LIB is None:
+        p = lib_path()
+        if not os.path.exists(p):
+            raise ImportError("liblc3plus_hip.so is not built (run `python -c 'import __graft_entry__ as g; g.build()'`); "
+                              "there is no fallback implementation")
+        L = C.CDLL(p)
+        L.lc3_enc_set_frame_ms.argtypes = [C.c_void_p, C.c_float]
+        L.lc3plus_enc_batch_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
+                                               C.POINTER(C.c_int), C.c_int]
+        L.lc3plus_enc_batch_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                               C.c_void_p, C.c_int]
+        L.lc3plus_enc_batch_encode_traced.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+        L.lc3plus_enc_batch_last_kernel_ms.restype = C.c_float
+        L.lc3plus_enc_batch_last_kernel_ms.argtypes = [C.c_void_p]
+        for f in ("lc3plus_enc_batch_destroy", "lc3plus_enc_batch_input_samples", "lc3plus_enc_batch_stride"):
+            getattr(L, f).argtypes = [C.c_void_p]
+        L.lc3plus_enc_batch_num_bytes.argtypes = [C.c_void_p, C.c_int]
+        L.lc3plus_enc_batch_set_bitrate.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.lc3plus_enc_batch_set_bandwidth.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.lc3_enc_fl.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.POINTER(C.c_int)]
+        _LIB = L
+    return _LIB
+
+
+class Batch:
+    """n_streams independent encoders (lc3plus_enc_batch_*), state resident on the GPU between encode() calls."""
+
+    def __init__(self, n_streams, samplerate, channels, frame_ms, hrmode, bitrates, device=-1):
+        self.lib = load_library()
+        br = (C.c_int * n_streams)(*[int(b) for b in bitrates])
+        self.h = C.c_void_p()
+        rc = self.lib.lc3plus_enc_batch_create(C.byref(self.h), n_streams, samplerate, channels, frame_ms, hrmode, br, device)
+        if rc:
+            raise LC3Error(rc, "lc3plus_enc_batch_create")
+        self.n_streams, self.channels = n_streams, channels
+        self.N = self.lib.lc3plus_enc_batch_input_samples(self.h)
+
+    @property
+    def stride(self):
+        return self.lib.lc3plus_enc_batch_stride(self.h)
+
+    def num_bytes(self, stream):
+        return self.lib.lc3plus_enc_batch_num_bytes(self.h, stream)
+
+    def set_bitrate(self, stream, bitrate):
+        return self.lib.lc3plus_enc_batch_set_bitrate(self.h, stream, bitrate)
+
+    def set_bandwidth(self, stream, bw):
+        return self.lib.lc3plus_enc_batch_set_bandwidth(self.h, stream, bw)
+
+    def encode(self, pcm, bitdepth=16):
+        """pcm: host array [n_streams, T, channels, N] (or [n_streams, T, N] for mono) -> uint8 [n_streams, T, stride]."""
+        pcm = np.ascontiguousarray(pcm)
+        T = pcm.shape[1]
+        stride = self.stride
+        out = np.zeros((self.n_streams, T, stride), dtype=np.uint8)
+        rc = self.lib.lc3plus_enc_batch_encode(self.h, pcm.ctypes.data, 0, bitdepth, T, out.ctypes.data, stride, 0, None, 1)
+        if rc:
+            raise LC3Error(rc, "lc3plus_enc_batch_encode")
+        return out
+
+    def encode_traced(self, pcm, bitdepth=16):
+        pcm = np.ascontiguousarray(pcm)
+        T = pcm.shape[1]
+        stride = self.stride
+        out = np.zeros((self.n_streams, T, stride), dtype=np.uint8)
+        tsz = self.lib.lc3plus_trace_sizeof()
+        traces = np.zeros((self.n_streams * self.channels * T, tsz), dtype=np.uint8)
+        rc = self.lib.lc3plus_enc_batch_encode_traced(self.h, pcm.ctypes.data, bitdepth, T, out.ctypes.data, stride, traces.ctypes.data)
+        if rc:
+            raise LC3Error(rc, "lc3plus_enc_batch_encode_traced")
+        return out, traces
+
+    def encode_device(self, d_pcm_ptr, bitdepth, T, d_out_ptr, out_stride, hip_stream=None, sync=False):
+        """Device-resident variant: raw device pointers (e.g. torch tensors' data_ptr())."""
+        rc = self.lib.lc3plus_enc_batch_encode(self.h, C.c_void_p(d_pcm_ptr), 1, bitdepth, T, C.c_void_p(d_out_ptr), out_stride, 1,
+                                               C.c_void_p(hip_stream) if hip_stream else None, 1 if sync else 0)
+        if rc:
+            raise LC3Error(rc, "lc3plus_enc_batch_encode(device)")
+
+    def last_kernel_ms(self):
+        return float(self.lib.lc3plus_enc_batch_last_kernel_ms(self.h))
+
+    def close(self):
+        if self.h:
+            self.lib.lc3plus_enc_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Encoder:
+    """Single-stream drop-in API (lc3_enc_*), mirrors how R/codec_exe.c:171-199,369-381 drives the reference."""
+
+    def __init__(self, samplerate, channels=1, frame_ms=10.0, hrmode=0, bitrate=64000):
+        L = self.lib = load_library()
+        size = L.lc3_enc_get_size(samplerate, channels)
+        if size <= 0:
+            raise LC3Error(4, "lc3_enc_get_size")
+        self.buf = C.create_string_buffer(size)
+        self.p = C.cast(self.buf, C.c_void_p)
+        self.channels = channels
+        for rc, what in ((L.lc3_enc_init(self.p, samplerate, channels), "init"), (L.lc3_enc_set_frame_ms(self.p, frame_ms), "frame_ms"),
+                         (L.lc3_enc_set_hrmode(self.p, hrmode), "hrmode"), (L.lc3_enc_set_bitrate(self.p, bitrate), "bitrate")):
+            if rc:
+                raise LC3Error(rc, what)
+        self.N = L.lc3_enc_get_input_samples(self.p)
+        self.nbytes = L.lc3_enc_get_num_bytes(self.p)
+
+    def encode(self, planar, bitdepth=16):
+        planar = np.ascontiguousarray(planar)
+        ptrs = (C.c_void_p * self.channels)(*[planar[c].ctypes.data for c in range(self.channels)])
+        out = np.zeros(self.nbytes, dtype=np.uint8)
+        nb = C.c_int(0)
+        rc = self.lib.lc3_enc_fl(self.p, ptrs, bitdepth, out.ctypes.data, C.byref(nb))
+        if rc:
+            raise LC3Error(rc, "lc3_enc_fl")
+        return out[:nb.value]
+
+    def close(self):
+        if self.p:
+            self.lib.lc3_free_encoder_structs(self.p)
+            self.p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

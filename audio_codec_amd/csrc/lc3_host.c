@@ -1,0 +1,537 @@
+/* lc3_host.c -- host side (plain C) of the MI355X LC3plus encode engine.
+ *
+ * Exports the reference's encoder ABI (include/lc3.h: lc3_enc_*, same semantics as R/lc3.c:102-309 with
+ * R = LC3plus_ETSI_src_v17171_20200723/src/floating_point) plus the batched extension (include/lc3plus_batch.h).
+ * All signal processing happens in the HIP kernels (lc3_kernels.hip) reached through lc3_shim.h; this file only
+ * derives configuration (R/setup_enc_lc3.c), builds the init-time tables with the host libm exactly where the
+ * reference evaluates them, and moves buffers.  There is no CPU encode path: without a HIP device every encode
+ * call fails with LC3_ERROR.
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../../include/lc3.h"
+#include "../../include/lc3plus_batch.h"
+#include "lc3_tables.h"
+#include "lc3_shim.h"
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+#define MAX_CH 2                    /* R/defines.h:121 */
+#define IMIN(a, b) ((a) < (b) ? (a) : (b))
+#define IMAX(a, b) ((a) > (b) ? (a) : (b))
+
+/* ------------------------------------------------------------------------------------------------ */
+/* configuration shared by the single-stream and the batch API                                       */
+/* ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    int fs, fs_in, fs_idx, channels, dms, hrmode;
+    float frame_ms;
+    int N, ylen, la, nbands, bw_bits, tilt;
+    int att_nblocks, att_hang; float att_damping, sns_damping;
+    const lc3t_cfg_t* tab;          /* NULL when the frame size has no window/band table */
+} geom_t;
+
+static int samplerate_ok(int sr)
+{
+    switch (sr) { case 8000: case 16000: case 24000: case 32000: case 44100: case 48000: case 96000: return 1; default: return 0; }
+}
+
+static void geom_init(geom_t* g, int samplerate, int channels)            /* R/setup_enc_lc3.c:31-70 */
+{
+    static const int tilts[6] = {14, 18, 22, 26, 30, 34};
+    memset(g, 0, sizeof *g);
+    g->fs = samplerate == 44100 ? 48000 : samplerate; g->fs_in = samplerate;
+    g->fs_idx = g->fs / 10000; if (g->fs_idx > 4) g->fs_idx = 5;
+    g->channels = channels; g->dms = 100; g->frame_ms = 10;
+    g->tilt = tilts[g->fs_idx];
+}
+
+static void geom_update(geom_t* g)                                        /* R/setup_enc_lc3.c:73-193 */
+{
+    g->N = g->fs / 100;
+    if (g->hrmode == 1) { g->ylen = g->N; g->sns_damping = 0.6; }
+    else { g->ylen = IMIN(400, g->N); g->sns_damping = 0.85; }
+    if (g->fs_idx == 5) g->hrmode = 1;                                    /* reference order kept */
+    g->bw_bits = g->hrmode ? 0 : lc3t_bw_bits[g->fs_idx];
+    if (g->dms == 100) { g->att_nblocks = 4; g->att_damping = 0.5; g->att_hang = 2; }
+    if (g->dms == 25) { g->N >>= 2; g->ylen /= 4; }
+    if (g->dms == 50) { g->N >>= 1; g->ylen /= 2; }
+    g->tab = NULL; g->nbands = 64; g->la = 0;
+    for (int i = 0; i < LC3T_NCFG; i++)
+        if (lc3t_cfg[i].valid && lc3t_cfg[i].fs_idx == g->fs_idx && lc3t_cfg[i].dms == g->dms && lc3t_cfg[i].hr == g->hrmode) g->tab = &lc3t_cfg[i];
+    if (g->tab) { g->nbands = g->tab->nbands; g->la = g->tab->la_zeros; }
+}
+
+/* the kernels are built for frame lengths up to LC3D_MAX_N whose N/2-point DFT is 240 (15x16) or 120 (8x3x5) */
+static int geom_supported(const geom_t* g) { return g->tab && g->N <= LC3D_MAX_N && (g->N == 480 || g->N == 240); }
+
+/* R/setup_enc_lc3.c:196-375: bitrate -> per-channel budgets.  Returns an LC3_Error. */
+static LC3_Error derive_bitrate(const geom_t* g, int bitrate, lc3d_chan* ch /* [channels] */)
+{
+    int minBR = 0, maxBR = 0;
+    if (g->hrmode) {
+        switch (g->dms) {
+        case 25: maxBR = 672000; minBR = g->fs == 48000 ? 172800 : g->fs == 96000 ? 198400 : -1; break;
+        case 50: maxBR = 600000; minBR = g->fs == 48000 ? 148800 : g->fs == 96000 ? 174400 : -1; break;
+        case 100: maxBR = 500000; minBR = g->fs == 48000 ? 124800 : g->fs == 96000 ? 149600 : -1; break;
+        default: return LC3_HRMODE_ERROR;
+        }
+        if (minBR < 0) return LC3_HRMODE_ERROR;
+    } else {
+        minBR = 20 * 8 * (1000 / g->frame_ms) * (g->fs_in == 44100 ? 441. / 480 : 1);
+        maxBR = 400 * 8 * (1000 / g->frame_ms) * (g->fs_in == 44100 ? 441. / 480 : 1);
+    }
+    minBR *= g->channels; maxBR *= g->channels;
+    if (bitrate < minBR || bitrate > maxBR) return LC3_BITRATE_ERROR;
+    const int totalBytes = bitrate * g->N / (8 * g->fs_in);
+    int off = 0;
+    for (int c = 0; c < g->channels; c++) {
+        lc3d_chan* s = &ch[c];
+        const int was_attack = s->attack_handling;
+        s->nbytes = totalBytes / g->channels + (c < (totalBytes % g->channels));
+        s->out_off = off; off += s->nbytes;
+        s->total_bits = s->nbytes << 3;
+        s->target_bits_init = s->total_bits - 38 - 8 - 3 - g->bw_bits - (int)ceil(log2f(g->N / 2)) - 2 - 1;
+        if (s->total_bits > 1280) s->target_bits_init -= 1;
+        if (s->total_bits > 2560) s->target_bits_init -= 1;
+        if (g->hrmode) s->target_bits_init -= 1;
+        s->lpc_weighting = s->total_bits < 480;
+        if (g->frame_ms == 5) s->lpc_weighting = s->total_bits < 240;
+        if (g->frame_ms == 2.5) s->lpc_weighting = s->total_bits < 120;
+        s->gg_off = -(IMIN(115, s->total_bits / (10 * (g->fs_idx + 1))) + 105 + 5 * (g->fs_idx + 1));
+        if (g->frame_ms == 10 && ((g->fs_in >= 44100 && s->nbytes >= 100) || (g->fs_in == 32000 && s->nbytes >= 81)) &&
+            s->nbytes < 340 && g->hrmode == 0) s->attack_handling = 1;
+        else { s->attack_handling = 0; s->reset_attack = 1; }
+        (void)was_attack;
+        int bitsTmp = s->total_bits;
+        if (g->frame_ms == 2.5) bitsTmp = bitsTmp * 4.0 * (1.0 - 0.4);
+        if (g->frame_ms == 5) bitsTmp = bitsTmp * 2 - 160;
+        s->ltpf_enable = bitsTmp < 640 + (g->fs_idx - 1) * 80;
+        if (g->hrmode) s->ltpf_enable = 0;
+        if (g->hrmode && g->fs_idx >= 4) {
+            int real_rate = s->nbytes * 8000 / g->frame_ms;
+            s->reg_bits = real_rate / 12500;
+            if (g->fs_idx == 5) { if (g->frame_ms == 10) s->reg_bits += 2; if (g->frame_ms == 2.5) s->reg_bits -= 6; }
+            else { if (g->frame_ms == 2.5) s->reg_bits -= 6; if (g->frame_ms == 10) s->reg_bits += 5; }
+        } else s->reg_bits = -1;
+    }
+    return LC3_OK;
+}
+
+/* ---- prime-factor index plan for the 120-point DFT (index logic of R/fft/fft_generic.h:634-699).
+ * The recursion is run on slot labels instead of samples: every leaf DFT records where its inputs live in the
+ * previous stage's output buffer; its outputs get consecutive slots.  The last stage's scatter is folded in. ---- */
+static int pfa_inverse(int a, int b)
+{
+    int b0 = b, x0 = 0, x1 = 1;
+    if (b == 1) return 1;
+    while (a > 1) { int q = a / b, t = b; b = a % b; a = t; t = x0; x0 = x1 - q * x0; x1 = t; }
+    if (x1 < 0) x1 += b0;
+    return x1;
+}
+typedef struct { uint8_t* src[3]; int count[3]; int leaf[3]; } pfa_rec;
+static void pfa_leaf(int* x, int n, pfa_rec* r)
+{
+    int st = n == r->leaf[0] ? 0 : n == r->leaf[1] ? 1 : 2;
+    for (int j = 0; j < n; j++) { r->src[st][r->count[st]] = (uint8_t)x[j]; x[j] = r->count[st]; r->count[st]++; }
+}
+static void pfa_label(int* x, int length, int* scratch, int nfac, const int* fac, pfa_rec* r)
+{
+    if (nfac <= 1) { pfa_leaf(x, length, r); return; }
+    int* tmp = scratch;
+    const int n2 = fac[0], n1 = length / n2, incr = n1 * pfa_inverse(n1, n2);
+    int idx = 0, cnt = 0;
+    for (int i = 0; i < n1; i++) {
+        for (int ii = 0; ii < n2 - 1; ii++) { tmp[cnt++] = x[idx]; idx += incr; if (idx > length) idx -= length; }
+        tmp[cnt++] = x[idx]; idx++;
+    }
+    for (cnt = 0; cnt < length; cnt += n2) pfa_leaf(tmp + cnt, n2, r);
+    for (cnt = 0; cnt < n1; cnt++) for (int i = 0; i < n2; i++) x[cnt + i * n1] = tmp[cnt * n2 + i];
+    for (cnt = 0; cnt < length; cnt += n1) pfa_label(x + cnt, n1, tmp, nfac - 1, fac + 1, r);
+    cnt = 0;
+    for (int i = 0; i < n2; i++) {
+        idx = i * n1;
+        for (int ii = 0; ii < n1; ii++) { tmp[idx] = x[cnt++]; idx += n2; if (idx > length) idx -= length; }
+    }
+    memcpy(x, tmp, sizeof(int) * length);
+}
+static void pfa_plan_120(lc3d_plan* p)
+{
+    static const int fac[3] = {8, 3, 5};
+    int x[120], scratch[240];
+    pfa_rec r; memset(&r, 0, sizeof r);
+    r.src[0] = p->pfa_src; r.src[1] = p->pfa_src + 120; r.src[2] = p->pfa_src + 240;
+    r.leaf[0] = 8; r.leaf[1] = 3; r.leaf[2] = 5;
+    for (int i = 0; i < 120; i++) x[i] = i;
+    pfa_label(x, 120, scratch, 3, fac, &r);
+    /* x[i] = slot of the last stage holding output bin i  ->  pfa_dst[slot] = i */
+    for (int i = 0; i < 120; i++) p->pfa_dst[x[i]] = (uint8_t)i;
+}
+
+/* R/util.h:109 cexpi with the reference's float argument conversion */
+static void cexpi_f(float x, float* re, float* im) { *re = cosf(x); *im = sinf(x); }
+
+static void build_plan(const geom_t* g, lc3d_plan* p)
+{
+    memset(p, 0, sizeof *p);
+    p->fs = g->fs; p->fs_idx = g->fs_idx; p->dms = g->dms; p->hrmode = g->hrmode; p->N = g->N; p->ylen = g->ylen; p->la = g->la;
+    p->nbands = g->nbands; p->bw_bits = g->bw_bits; p->fft_len = g->N / 2; p->channels = g->channels;
+    p->rs_mem_in_len = 2 * 8 * g->fs / 12800;                              /* R/setup_enc_lc3.c:48 */
+    p->rs_stride = lc3t_rs_upfac[g->fs_idx]; p->rs_scale = lc3t_rs_scale[g->fs_idx];
+    p->len12 = g->dms == 25 ? 32 : g->dms == 50 ? 64 : 128; p->n12 = g->N * 12800 / g->fs;
+    p->ltpf_mem_len = g->dms == 25 ? 232 + 32 : 232;
+    p->att_nblocks = g->att_nblocks; p->att_hang = g->att_hang; p->att_damping = g->att_damping; p->sns_damping = g->sns_damping;
+    p->bw_cls = g->dms == 25 ? 0 : g->dms == 50 ? 1 : 2;
+    p->win_off = g->tab->win_off; p->band_off = g->tab->band_off; p->tilt = g->tilt; p->frame_ms = g->frame_ms;
+    const int len = g->N;
+    for (int i = 0; i < len / 2; i++) {                                   /* R/dct4.c:58-61 */
+        cexpi_f(-M_PI * (i + 0.25) / len, &p->tw1[2 * i], &p->tw1[2 * i + 1]);
+        cexpi_f(-M_PI * i / len, &p->tw2[2 * i], &p->tw2[2 * i + 1]);
+    }
+    p->dct4_norm = 1.0 / sqrtf(len / 2);                                   /* R/dct4.c:82 */
+    for (int i = 0; i < 16; i++) {                                         /* R/dct4.c:43-45 */
+        float cr, ci, sr = 2 / sqrtf(2 * 16), si = 0;
+        cexpi_f(-M_PI * i / (2 * 16), &cr, &ci);
+        p->dct2_tw[2 * i] = cr * sr - ci * si;
+        p->dct2_tw[2 * i + 1] = ci * sr + cr * si;
+    }
+    for (int i = 0; i < 16; i++) for (int j = 0; j < 16; j++)              /* R/sns_quantize_scf.c:30 */
+        p->idct_cos[i * 16 + j] = cos(M_PI / (2.0 * (float)16) * (2.0 * ((float)i + 1.0) - 1.0) * ((float)j));
+    p->c_idct_n1 = sqrtf(2.0 / (float)16); p->c_idct_n2 = 1.0 / (sqrtf(2.0));
+    for (int i = 0; i < 64; i++)                                           /* R/sns_compute_scf.c:91 */
+        p->sns_preemph[i] = powf(10.0, (float)i * (float)g->tilt / ((float)64 - 1.0) / 10.0);
+    for (int k = -256; k < 256; k++) {
+        float ind = (float)k;                                              /* R/estimate_global_gain.c:136: (ind + off) is a float holding k */
+        p->gain_est[k + 256] = powf(10.0, (ind / 28.0));
+        p->gain_adj[k + 256] = powf(10, (float)(k) / 28);                  /* R/adjust_global_gain.c:47 */
+    }
+    p->c_1em5_a = powf(10.0, -5.0); p->c_1em5_b = powf(10, -5); p->c_1em4 = powf(10.0, -40.0 / 10.0);
+    p->c_2m32 = powf(2.0, -32.0); p->c_2m31 = powf(2, -31); p->c_2m24 = powf(2, -24); p->c_2p15 = powf(2, 15); p->c_2p100 = powf(2, 100);
+    p->c_sqrt2 = sqrtf(2);
+    memset(p->band_of_bin, 255, sizeof p->band_of_bin);
+    const uint16_t* be = &lc3t_band_pool[g->tab->band_off];
+    for (int b = 0; b < g->nbands; b++) for (int j = be[b]; j < be[b + 1] && j < LC3D_MAX_N; j++) p->band_of_bin[j] = (uint8_t)b;
+    if (g->N / 2 == 120) pfa_plan_120(p);
+}
+
+static void init_state(float* st)                                         /* zeroed EncSetup + olpa_mem_pitch = 17 (R/setup_enc_lc3.c:178) */
+{
+    memset(st, 0, sizeof(float) * LC3D_STATE_WORDS);
+    ((int*)(st + LC3D_ST_SCAL))[LC3D_S_OLPA_PITCH] = 17;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* batch object                                                                                      */
+/* ------------------------------------------------------------------------------------------------ */
+struct lc3plus_batch {
+    geom_t g; int n_streams; int stride;
+    lc3d_chan* chans;               /* [n_streams * channels] host mirror */
+    int* bitrates;
+    void* dev;
+};
+
+static LC3_Error batch_upload(lc3plus_batch* b, int first_stream, int count)
+{
+    const int C = b->g.channels;
+    if (lc3hip_upload_chans(b->dev, b->chans + (size_t)first_stream * C, first_stream * C, count * C)) return LC3_ERROR;
+    return LC3_OK;
+}
+
+static void batch_restride(lc3plus_batch* b)
+{
+    int s = 0;
+    for (int i = 0; i < b->n_streams; i++) { int n = 0; for (int c = 0; c < b->g.channels; c++) n += b->chans[i * b->g.channels + c].nbytes; s = IMAX(s, n); }
+    b->stride = s;
+}
+
+LC3_Error lc3plus_enc_batch_create(lc3plus_batch** out, int n_streams, int samplerate, int channels, float frame_ms, int hrmode,
+                                   const int* bitrates, int device)
+{
+    if (!out || !bitrates) return LC3_NULL_ERROR;
+    *out = NULL;
+    if (n_streams <= 0) return LC3_ERROR;
+    if (!samplerate_ok(samplerate)) return LC3_SAMPLERATE_ERROR;
+    if (channels < 1 || channels > MAX_CH) return LC3_CHANNELS_ERROR;
+    { int d = (int)ceil(frame_ms * 10); if (d != 25 && d != 50 && d != 100) return LC3_FRAMEMS_ERROR; }
+    if (samplerate < 48000 && hrmode != 0) return LC3_SAMPLERATE_ERROR;
+    lc3plus_batch* b = (lc3plus_batch*)calloc(1, sizeof *b);
+    if (!b) return LC3_ERROR;
+    geom_init(&b->g, samplerate, channels);
+    b->g.dms = (int)(frame_ms * 10); b->g.frame_ms = frame_ms; b->g.hrmode = hrmode > 0;
+    geom_update(&b->g);
+    if (b->g.fs_idx == 5 && b->g.hrmode == 0) { free(b); return LC3_HRMODE_ERROR; }
+    if (!geom_supported(&b->g)) {
+        fprintf(stderr, "lc3plus_hip: %d Hz / %.1f ms%s is not built into the gfx950 kernels yet\n", samplerate, frame_ms, hrmode ? " hr" : "");
+        free(b); return LC3_ERROR;
+    }
+    b->n_streams = n_streams;
+    b->chans = (lc3d_chan*)calloc((size_t)n_streams * channels, sizeof(lc3d_chan));
+    b->bitrates = (int*)calloc(n_streams, sizeof(int));
+    if (!b->chans || !b->bitrates) { free(b->chans); free(b->bitrates); free(b); return LC3_ERROR; }
+    for (int i = 0; i < n_streams; i++) {
+        LC3_Error e = derive_bitrate(&b->g, bitrates[i], b->chans + (size_t)i * channels);
+        if (e) { free(b->chans); free(b->bitrates); free(b); return e; }
+        for (int c = 0; c < channels; c++) b->chans[i * channels + c].reset_attack = 0;
+        b->bitrates[i] = bitrates[i];
+    }
+    batch_restride(b);
+    lc3d_plan* plan = (lc3d_plan*)malloc(sizeof *plan);
+    float st[LC3D_STATE_WORDS];
+    build_plan(&b->g, plan);
+    init_state(st);
+    int rc = lc3hip_create(&b->dev, plan, n_streams, device);
+    free(plan);
+    if (!rc) rc = lc3hip_reset_state(b->dev, st);
+    if (!rc) rc = batch_upload(b, 0, n_streams) != LC3_OK;
+    if (rc) { if (b->dev) lc3hip_destroy(b->dev); free(b->chans); free(b->bitrates); free(b); return LC3_ERROR; }
+    *out = b;
+    return LC3_OK;
+}
+
+LC3_Error lc3plus_enc_batch_destroy(lc3plus_batch* b)
+{
+    if (!b) return LC3_NULL_ERROR;
+    lc3hip_destroy(b->dev);
+    free(b->chans); free(b->bitrates); free(b);
+    return LC3_OK;
+}
+
+int lc3plus_enc_batch_input_samples(const lc3plus_batch* b) { return b ? b->g.N : 0; }
+int lc3plus_enc_batch_stride(const lc3plus_batch* b) { return b ? b->stride : 0; }
+int lc3plus_enc_batch_num_bytes(const lc3plus_batch* b, int stream)
+{
+    if (!b || stream < 0 || stream >= b->n_streams) return 0;
+    int n = 0;
+    for (int c = 0; c < b->g.channels; c++) n += b->chans[stream * b->g.channels + c].nbytes;
+    return n;
+}
+
+LC3_Error lc3plus_enc_batch_set_bitrate(lc3plus_batch* b, int stream, int bitrate)
+{
+    if (!b) return LC3_NULL_ERROR;
+    if (stream < 0 || stream >= b->n_streams) return LC3_ERROR;
+    if (bitrate <= 0) return LC3_BITRATE_ERROR;
+    lc3d_chan tmp[MAX_CH];
+    memcpy(tmp, b->chans + (size_t)stream * b->g.channels, sizeof(lc3d_chan) * b->g.channels);
+    for (int c = 0; c < b->g.channels; c++) tmp[c].reset_attack = 0;
+    LC3_Error e = derive_bitrate(&b->g, bitrate, tmp);
+    if (e) return e;
+    memcpy(b->chans + (size_t)stream * b->g.channels, tmp, sizeof(lc3d_chan) * b->g.channels);
+    b->bitrates[stream] = bitrate;
+    batch_restride(b);
+    return batch_upload(b, stream, 1);
+}
+
+LC3_Error lc3plus_enc_batch_set_bandwidth(lc3plus_batch* b, int stream, int bandwidth)   /* R/lc3.c:187-208 */
+{
+    if (!b) return LC3_NULL_ERROR;
+    if (stream < 0 || stream >= b->n_streams) return LC3_ERROR;
+    if (b->g.hrmode == 1) return LC3_HRMODE_BW_ERROR;
+    lc3d_chan* ch = b->chans + (size_t)stream * b->g.channels;
+    int eff = b->g.fs_in;
+    if (ch[0].bandwidth != bandwidth) {
+        if (b->g.fs_in > 40000) eff = 40000;
+        if (bandwidth * 2 > eff) return LC3_BW_WARNING;
+        for (int c = 0; c < b->g.channels; c++) {
+            ch[c].bandwidth = bandwidth;
+            ch[c].bw_cut_bin = (bandwidth * b->g.dms) / 5000;
+            ch[c].bw_index = IMAX(0, (bandwidth / 4000) - 1);
+        }
+        return batch_upload(b, stream, 1);
+    }
+    return LC3_OK;
+}
+
+static LC3_Error batch_encode(lc3plus_batch* b, const void* pcm, int pcm_on_device, int bitdepth, int n_frames, void* out, int out_stride,
+                              int out_on_device, void* hip_stream, int sync, void* trace)
+{
+    if (!b || !pcm || !out) return LC3_NULL_ERROR;
+    if (bitdepth != 16 && bitdepth != 24 && bitdepth != 32) return LC3_ERROR;
+    if (n_frames <= 0 || out_stride < b->stride) return LC3_ERROR;
+    if (lc3hip_encode(b->dev, pcm, pcm_on_device, bitdepth, n_frames, out, out_stride, out_on_device, hip_stream, sync, trace)) return LC3_ERROR;
+    /* one-shot attack-state reset requests have been consumed by this launch */
+    int dirty = 0;
+    for (int i = 0; i < b->n_streams * b->g.channels; i++) if (b->chans[i].reset_attack) { b->chans[i].reset_attack = 0; dirty = 1; }
+    if (dirty) return batch_upload(b, 0, b->n_streams);
+    return LC3_OK;
+}
+
+LC3_Error lc3plus_enc_batch_encode(lc3plus_batch* b, const void* pcm, int pcm_on_device, int bitdepth, int n_frames, void* out,
+                                   int out_stride, int out_on_device, void* hip_stream, int sync)
+{
+    return batch_encode(b, pcm, pcm_on_device, bitdepth, n_frames, out, out_stride, out_on_device, hip_stream, sync, NULL);
+}
+
+/* debug / stage-parity entry point used by tests: additionally returns one lc3d_trace per channel-frame */
+LC3_Error lc3plus_enc_batch_encode_traced(lc3plus_batch* b, const void* pcm, int bitdepth, int n_frames, void* out, int out_stride, void* traces)
+{
+    return batch_encode(b, pcm, 0, bitdepth, n_frames, out, out_stride, 0, NULL, 1, traces);
+}
+int lc3plus_trace_sizeof(void) { return (int)sizeof(lc3d_trace); }
+
+float lc3plus_enc_batch_last_kernel_ms(lc3plus_batch* b) { return b ? lc3hip_last_ms(b->dev) : 0.0f; }
+
+/* ------------------------------------------------------------------------------------------------ */
+/* single-stream drop-in API (R/lc3.h:163-295)                                                       */
+/* ------------------------------------------------------------------------------------------------ */
+struct LC3_Enc {
+    /* R/codec_exe.c:298-320 reads these three fields of the reference struct directly; keep the names */
+    int bitrate, epmode, bandwidth;
+    int lc3_br_set, channels, samplerate, hrmode; float frame_ms;
+    geom_t g;
+    lc3d_chan ch[MAX_CH];
+    lc3plus_batch* batch;           /* batch of one stream, created lazily at the first encode */
+    int16_t* stage16; int32_t* stage32; uint8_t* stage_out;
+    unsigned magic;
+};
+#define ENC_MAGIC 0x4C433350u
+
+int lc3_version(void) { return LC3_VERSION; }
+int lc3_channels_supported(int channels) { return channels >= 1 && channels <= MAX_CH; }
+int lc3_samplerate_supported(int samplerate) { return samplerate_ok(samplerate); }
+
+int lc3_enc_get_size(int samplerate, int channels)
+{
+    if (!lc3_samplerate_supported(samplerate) || !lc3_channels_supported(channels)) return 0;
+    return (int)sizeof(struct LC3_Enc);
+}
+
+static void enc_drop_device(LC3_Enc* e)
+{
+    if (e->batch) { lc3plus_enc_batch_destroy(e->batch); e->batch = NULL; }
+    free(e->stage16); free(e->stage32); free(e->stage_out); e->stage16 = NULL; e->stage32 = NULL; e->stage_out = NULL;
+}
+
+LC3_Error lc3_enc_init(LC3_Enc* e, int samplerate, int channels)
+{
+    if (e == NULL) return LC3_NULL_ERROR;
+    if ((uintptr_t)e % 4 != 0) return LC3_ALIGN_ERROR;
+    if (!lc3_samplerate_supported(samplerate)) return LC3_SAMPLERATE_ERROR;
+    if (!lc3_channels_supported(channels)) return LC3_CHANNELS_ERROR;
+    memset(e, 0, sizeof *e);
+    e->magic = ENC_MAGIC; e->channels = channels; e->samplerate = samplerate; e->frame_ms = 10;
+    geom_init(&e->g, samplerate, channels);
+    geom_update(&e->g);
+    return LC3_OK;
+}
+
+LC3_Error lc3_enc_set_frame_ms(LC3_Enc* e, float frame_ms)
+{
+    if (e == NULL) return LC3_NULL_ERROR;
+    { int d = (int)ceil(frame_ms * 10); if (d != 25 && d != 50 && d != 100) return LC3_FRAMEMS_ERROR; }
+    if (e->lc3_br_set) return LC3_BITRATE_SET_ERROR;
+    e->g.dms = (int)(frame_ms * 10); e->g.frame_ms = frame_ms; e->frame_ms = frame_ms;
+    geom_update(&e->g);
+    enc_drop_device(e);
+    return LC3_OK;
+}
+
+LC3_Error lc3_enc_set_hrmode(LC3_Enc* e, int hrmode)
+{
+    if (e == NULL) return LC3_NULL_ERROR;
+    if (e->g.fs_in < 48000 && hrmode != 0) return LC3_SAMPLERATE_ERROR;
+    e->g.hrmode = hrmode > 0; e->hrmode = e->g.hrmode;
+    geom_update(&e->g);
+    enc_drop_device(e);
+    return LC3_OK;
+}
+
+LC3_Error lc3_enc_set_bitrate(LC3_Enc* e, int bitrate)
+{
+    if (e == NULL) return LC3_NULL_ERROR;
+    if (bitrate <= 0) return LC3_BITRATE_ERROR;
+    if (e->g.fs_idx == 5 && e->g.hrmode == 0) return LC3_HRMODE_ERROR;
+    lc3d_chan tmp[MAX_CH];
+    memcpy(tmp, e->ch, sizeof tmp);
+    LC3_Error err = derive_bitrate(&e->g, bitrate, tmp);
+    if (err) return err;
+    memcpy(e->ch, tmp, sizeof tmp);
+    e->lc3_br_set = 1; e->bitrate = bitrate;
+    if (e->batch) return lc3plus_enc_batch_set_bitrate(e->batch, 0, bitrate);
+    return LC3_OK;
+}
+
+LC3_Error lc3_enc_set_bandwidth(LC3_Enc* e, int bandwidth)
+{
+    if (e == NULL) return LC3_NULL_ERROR;
+    if (e->g.hrmode == 1) return LC3_HRMODE_BW_ERROR;
+    int eff = e->g.fs_in;
+    if (e->bandwidth != bandwidth) {
+        if (e->g.fs_in > 40000) eff = 40000;
+        if (bandwidth * 2 > eff) return LC3_BW_WARNING;
+        e->bandwidth = bandwidth;
+        for (int c = 0; c < e->channels; c++) {
+            e->ch[c].bandwidth = bandwidth; e->ch[c].bw_cut_bin = (bandwidth * e->g.dms) / 5000; e->ch[c].bw_index = IMAX(0, (bandwidth / 4000) - 1);
+        }
+        if (e->batch) return lc3plus_enc_batch_set_bandwidth(e->batch, 0, bandwidth);
+    }
+    return LC3_OK;
+}
+
+int lc3_enc_get_input_samples(const LC3_Enc* e) { return e ? e->g.N : 0; }
+int lc3_enc_get_num_bytes(const LC3_Enc* e) { return e ? e->ch[0].nbytes * e->channels : 0; }   /* R/lc3.c:124-129 (sic) */
+int lc3_enc_get_delay(const LC3_Enc* e) { return e ? e->g.N - 2 * e->g.la : 0; }
+int lc3_enc_get_real_bitrate(const LC3_Enc* e)
+{
+    if (e == NULL) return 0;
+    if (!e->lc3_br_set) return LC3_BITRATE_UNSET_ERROR;
+    int tot = 0;
+    for (int c = 0; c < e->channels; c++) tot += e->ch[c].nbytes;
+    int br = (tot * 80000) / e->g.dms;
+    if (e->g.fs_in == 44100) { int rem = br % 480; br = ((br - rem) / 480) * 441 + (rem * 441) / 480; }
+    return br;
+}
+
+LC3_Error lc3_enc_fl(LC3_Enc* e, void** input_samples, int bitdepth, void* output_bytes, int* num_bytes)
+{
+    if (!e || !input_samples || !output_bytes || !num_bytes) return LC3_NULL_ERROR;
+    for (int c = 0; c < e->channels; c++) if (input_samples[c] == NULL) return LC3_NULL_ERROR;
+    if (bitdepth != 16 && bitdepth != 24 && bitdepth != 32) return LC3_ERROR;
+    if (!e->lc3_br_set) return LC3_BITRATE_UNSET_ERROR;
+    const int N = e->g.N, C = e->channels;
+    if (!e->batch) {
+        LC3_Error err = lc3plus_enc_batch_create(&e->batch, 1, e->g.fs_in, C, e->g.frame_ms, e->g.hrmode, &e->bitrate, -1);
+        if (err) return err == LC3_BITRATE_ERROR ? err : LC3_ERROR;
+        if (e->bandwidth) lc3plus_enc_batch_set_bandwidth(e->batch, 0, e->bandwidth);
+        e->stage16 = (int16_t*)malloc(sizeof(int16_t) * C * LC3D_MAX_N);
+        e->stage32 = (int32_t*)malloc(sizeof(int32_t) * C * LC3D_MAX_N);
+        e->stage_out = (uint8_t*)malloc(LC3_MAX_BYTES);
+        if (!e->stage16 || !e->stage32 || !e->stage_out) return LC3_ERROR;
+    }
+    const void* pcm;
+    if (bitdepth == 16) { for (int c = 0; c < C; c++) memcpy(e->stage16 + c * N, input_samples[c], sizeof(int16_t) * N); pcm = e->stage16; }
+    else { for (int c = 0; c < C; c++) memcpy(e->stage32 + c * N, input_samples[c], sizeof(int32_t) * N); pcm = e->stage32; }
+    const int nb = lc3plus_enc_batch_num_bytes(e->batch, 0);
+    LC3_Error err = lc3plus_enc_batch_encode(e->batch, pcm, 0, bitdepth, 1, output_bytes, nb, 0, NULL, 1);
+    if (err) return err;
+    *num_bytes = nb;
+    return LC3_OK;
+}
+LC3_Error lc3_enc16(LC3_Enc* e, int16_t** in, void* out, int* nb) { return lc3_enc_fl(e, (void**)in, 16, out, nb); }
+LC3_Error lc3_enc24(LC3_Enc* e, int32_t** in, void* out, int* nb) { return lc3_enc_fl(e, (void**)in, 24, out, nb); }
+LC3_Error lc3_enc32(LC3_Enc* e, int32_t** in, void* out, int* nb) { return lc3_enc_fl(e, (void**)in, 32, out, nb); }
+
+LC3_Error lc3_free_encoder_structs(LC3_Enc* e)
+{
+    if (!e) return LC3_NULL_ERROR;
+    if (e->magic == ENC_MAGIC) enc_drop_device(e);
+    return LC3_OK;
+}
+LC3_Error lc3_enc_free_memory(LC3_Enc* e)
+{
+    if (!e) return LC3_NULL_ERROR;
+    lc3_free_encoder_structs(e);
+    free(e);
+    return LC3_OK;
+}
+
+/* lc3plus_enc_* aliases (north-star wording) */
+LC3_Error lc3plus_enc_init(LC3_Enc* e, int sr, int ch) { return lc3_enc_init(e, sr, ch); }
+LC3_Error lc3plus_enc_set_frame_ms(LC3_Enc* e, float ms) { return lc3_enc_set_frame_ms(e, ms); }
+LC3_Error lc3plus_enc_set_hrmode(LC3_Enc* e, int hr) { return lc3_enc_set_hrmode(e, hr); }
+LC3_Error lc3plus_enc_set_bitrate(LC3_Enc* e, int br) { return lc3_enc_set_bitrate(e, br); }
+LC3_Error lc3plus_enc16(LC3_Enc* e, int16_t** in, void* out, int* nb) { return lc3_enc16(e, in, out, nb); }
+int lc3plus_enc_get_size(int sr, int ch) { return lc3_enc_get_size(sr, ch); }

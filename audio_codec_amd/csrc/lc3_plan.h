@@ -1,0 +1,62 @@
+/* lc3_plan.h -- structures shared by the host C code (lc3_host.c) and the HIP kernels (lc3_kernels.hip).
+ *
+ * lc3d_plan : everything that is constant for a batch (geometry derived as in R/setup_enc_lc3.c:73-193 and
+ *             the init-time tables the reference builds with libm at start-up: DCT-IV twiddles R/dct4.c:51-63,
+ *             DCT-II(16) twiddles R/dct4.c:43-45, IDCT-II cosines R/sns_quantize_scf.c:30, SNS pre-emphasis
+ *             R/sns_compute_scf.c:91, global-gain powers R/estimate_global_gain.c:136 / R/adjust_global_gain.c:47).
+ *             Built on the host with the host libm -- exactly where the reference evaluates them -- and uploaded once.
+ * lc3d_chan : per channel-stream bitrate-derived values (R/setup_enc_lc3.c:196-375).
+ * State     : per channel-stream cross-frame state (R/setup_enc_lc3.h:17-62), LC3D_STATE_WORDS 32-bit words in HBM.
+ */
+#ifndef LC3_PLAN_H
+#define LC3_PLAN_H
+#include <stdint.h>
+
+#define LC3D_MAX_N 480          /* largest frame length built so far (48 kHz / 10 ms, 96 kHz / 2.5-5 ms) */
+#define LC3D_GAIN_TAB 512       /* gain index k = ind + gg_off in [-256, 255] -> tab[k + 256] */
+
+typedef struct {
+    int32_t fs, fs_idx, dms, hrmode, N, ylen, la, nbands, bw_bits, fft_len, channels;
+    int32_t rs_mem_in_len, rs_stride, len12, n12, ltpf_mem_len;
+    int32_t att_nblocks, att_hang, bw_cls, win_off, band_off, tilt;
+    float   att_damping, sns_damping, rs_scale, frame_ms, dct4_norm;
+    /* float constants the reference obtains from powf()/sqrtf() at run time with constant arguments */
+    float   c_1em5_a;           /* powf(10.0,-5.0)  R/olpa.c:112 */
+    float   c_1em5_b;           /* powf(10,-5)      R/ltpf_coder.c:97 */
+    float   c_1em4;             /* powf(10.0,-4.0)  R/sns_compute_scf.c:101 */
+    float   c_2m32, c_2m31, c_2m24, c_2p15, c_2p100;
+    float   c_sqrt2;            /* sqrtf(2) */
+    float   c_idct_n1, c_idct_n2;   /* R/sns_quantize_scf.c:24-25 */
+    float   pad0;
+    float   tw1[LC3D_MAX_N], tw2[LC3D_MAX_N];      /* N/2 complex (re,im) pairs each */
+    float   dct2_tw[32];
+    float   sns_preemph[64];
+    float   gain_est[LC3D_GAIN_TAB];               /* powf(10, (k)/28.0)  (double division) */
+    float   gain_adj[LC3D_GAIN_TAB];               /* powf(10, (float)k/28) (float division) */
+    double  idct_cos[256];
+    uint8_t band_of_bin[LC3D_MAX_N];
+    uint8_t pfa_src[360];       /* N/2 = 120 prime-factor DFT: gather maps of the 8-, 3- and 5-point stages */
+    uint8_t pfa_dst[120];       /* final scatter of the 5-point stage */
+} lc3d_plan;
+
+typedef struct {
+    int32_t nbytes, total_bits, target_bits_init, lpc_weighting, ltpf_enable, gg_off, attack_handling, reg_bits;
+    int32_t out_off;            /* byte offset of this channel's payload inside the stream-frame */
+    int32_t bandwidth, bw_cut_bin, bw_index;
+    int32_t reset_attack;       /* set by a bitrate change that disables attack handling (R/setup_enc_lc3.c:297-308) */
+    int32_t pad[3];
+} lc3d_chan;
+
+/* ---- state layout (32-bit words) ---- */
+#define LC3D_ST_XPREV   0                         /* previous frame's input samples as float [LC3D_MAX_N] */
+#define LC3D_ST_H12     (LC3D_ST_XPREV + LC3D_MAX_N)   /* last 384 samples of the HP-filtered 12.8 kHz stream */
+#define LC3D_H12_KEEP   384
+#define LC3D_ST_H6      (LC3D_ST_H12 + LC3D_H12_KEEP)  /* last 194 samples of the 6.4 kHz stream */
+#define LC3D_H6_KEEP    194
+#define LC3D_ST_SCAL    (LC3D_ST_H6 + LC3D_H6_KEEP + 2)
+enum { LC3D_S_HP0 = 0, LC3D_S_HP1, LC3D_S_OLPA_PITCH, LC3D_S_LTPF_NC1, LC3D_S_LTPF_NC2, LC3D_S_LTPF_PITCH, LC3D_S_LTPF_ON,
+       LC3D_S_ATT_M0, LC3D_S_ATT_M1, LC3D_S_ATT_ACC, LC3D_S_ATT_POS, LC3D_S_ATT_FLAG, LC3D_S_TBITS_OFF, LC3D_S_MEM_TARGET,
+       LC3D_S_MEM_SPEC, LC3D_S_COUNT };
+#define LC3D_STATE_WORDS 1088
+
+#endif

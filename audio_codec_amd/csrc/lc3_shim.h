@@ -1,0 +1,29 @@
+/* lc3_shim.h -- the thin C-ABI between the host C code (lc3_host.c) and the HIP side (lc3_kernels.hip). */
+#ifndef LC3_SHIM_H
+#define LC3_SHIM_H
+#include <stdint.h>
+#include "lc3_plan.h"
+
+/* per channel-frame intermediates (debug / stage-level parity tests); same field order as oracle/lc3_oracle.h:lc3o_trace */
+typedef struct {
+    float spec_mdct[960]; float s12k8[129]; int T0; float normcorr; int ltpf_param[3]; int ltpf_bits; int attack;
+    float ener[64]; int bw_idx; float scf[16]; int scf_idx[7]; float scf_q[16]; float spec_shaped[960];
+    int tns_nfilt, tns_order[2], tns_rc_idx[16], tns_bits; float spec_tns[960];
+    int target_bits_quant; float gain0; int gg_idx0, gg_min; int nbits0; float gain; int gg_idx, gain_change;
+    int nbits, nbits2, lastnz, lsb_mode; int xq[960]; int fac_ns; int n_res_bits; int bp_side, mask_side;
+} lc3d_trace;
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+int   lc3hip_create(void** ctx, const lc3d_plan* plan, int n_streams, int device);
+int   lc3hip_reset_state(void* ctx, const float* init_state_one);
+int   lc3hip_upload_chans(void* ctx, const lc3d_chan* chans, int first, int count);
+int   lc3hip_encode(void* ctx, const void* pcm, int pcm_on_device, int bitdepth, int n_frames, void* out, int out_stride,
+                    int out_on_device, void* hip_stream, int sync, void* trace_host);
+float lc3hip_last_ms(void* ctx);
+int   lc3hip_destroy(void* ctx);
+#ifdef __cplusplus
+}
+#endif
+#endif

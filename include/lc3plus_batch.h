@@ -1,0 +1,57 @@
+/* lc3plus_batch.h -- batched multi-stream extension of the lc3_enc_* ABI (new in this engine).
+ *
+ * The reference encodes one frame of one stream per call (R/lc3.c:226-234 -> R/enc_lc3_fl.c:162-174).
+ * Frames of ONE stream are not independent (MDCT overlap, pitch / LTPF memories and the rate-control
+ * loop persist, R/setup_enc_lc3.h:17-62), but streams (and channels, R/enc_lc3_fl.c:167-171) are.
+ * A batch therefore is n_streams independent encoder instances with identical (samplerate, frame_ms,
+ * hrmode, channels) and a per-stream bitrate; each encode() call advances every stream by n_frames
+ * frames with the per-stream state resident in HBM between calls.  One wavefront encodes one
+ * channel-stream.  Plain pointers and sizes only.
+ */
+#ifndef LC3PLUS_BATCH_H
+#define LC3PLUS_BATCH_H
+#include "lc3.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lc3plus_batch lc3plus_batch;
+
+/* Creates n_streams encoders on HIP device `device` (-1 = current).  bitrates[n_streams] is the total
+ * bitrate per stream (all channels), validated like lc3_enc_set_bitrate.  Error codes as lc3_enc_*. */
+LC3_Error lc3plus_enc_batch_create(lc3plus_batch** batch, int n_streams, int samplerate, int channels,
+                                   float frame_ms, int hrmode, const int* bitrates, int device);
+LC3_Error lc3plus_enc_batch_destroy(lc3plus_batch* batch);
+
+int lc3plus_enc_batch_input_samples(const lc3plus_batch* batch);    /* samples per channel per frame */
+int lc3plus_enc_batch_num_bytes(const lc3plus_batch* batch, int stream); /* bytes per frame of that stream */
+int lc3plus_enc_batch_stride(const lc3plus_batch* batch);           /* max over streams of num_bytes */
+LC3_Error lc3plus_enc_batch_set_bitrate(lc3plus_batch* batch, int stream, int bitrate);
+LC3_Error lc3plus_enc_batch_set_bandwidth(lc3plus_batch* batch, int stream, int bandwidth);
+
+/* Advances every stream by n_frames.
+ *   pcm : [n_streams][n_frames][channels][input_samples] samples, int16_t (bitdepth 16) or int32_t (24/32)
+ *   out : [n_streams][n_frames][out_stride] bytes; frame payload = num_bytes(stream) bytes, rest untouched
+ *   *_on_device : 0 = host pointer (copied with hipMemcpyAsync), 1 = device pointer used in place
+ *   hip_stream  : hipStream_t to enqueue on (NULL = the batch's own stream); the call returns after the
+ *                 work is complete when sync != 0, otherwise right after enqueueing.                  */
+LC3_Error lc3plus_enc_batch_encode(lc3plus_batch* batch, const void* pcm, int pcm_on_device, int bitdepth,
+                                   int n_frames, void* out, int out_stride, int out_on_device,
+                                   void* hip_stream, int sync);
+
+/* Kernel-only timing of the last encode() call in milliseconds (HIP events on the launch stream). */
+float lc3plus_enc_batch_last_kernel_ms(lc3plus_batch* batch);
+
+/* lc3plus_enc_* spellings of the single-stream API (north-star wording); thin aliases. */
+LC3_Error lc3plus_enc_init(LC3_Enc* e, int samplerate, int channels);
+LC3_Error lc3plus_enc_set_frame_ms(LC3_Enc* e, float frame_ms);
+LC3_Error lc3plus_enc_set_hrmode(LC3_Enc* e, int hrmode);
+LC3_Error lc3plus_enc_set_bitrate(LC3_Enc* e, int bitrate);
+LC3_Error lc3plus_enc16(LC3_Enc* e, int16_t** input_samples, void* output_bytes, int* num_bytes);
+int       lc3plus_enc_get_size(int samplerate, int channels);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

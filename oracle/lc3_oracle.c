@@ -815,7 +815,6 @@ static void poly_to_rc(float* a, float* out, int len)
     const int len0 = len;
     float buf[9] = {0};
     memset(out, 0, sizeof(float) * (len - 1));
-    for (int i = len - 1; i >= 0; i--) { /* a[i] /= a[0] in index order 0..len-1; a[0] becomes 1 first */ }
     { float a0 = a[0]; for (int i = 0; i < len; i++) { a[i] = a[i] / a0; a0 = a[0]; } }
     out[len - 1] = a[len - 1];
     for (int k = len - 2; k >= 0; k--) {
@@ -963,7 +962,7 @@ static void stage_gain_estimate(const lc3o_enc* e, chan_t* s, const float* x, in
         ind = (ind_min > offset ? ind_min : offset) - off;
     }
     *qmin = ind_min; *qgain = ind;
-    *gain = m_powf(10.0, ((ind + off) / 28.0));
+    *gain = powf(10.0, ((ind + off) / 28.0));   /* product: host-side libm table, both math modes */
 }
 
 /* R/quantize_spec.c:26-197 */
@@ -1039,7 +1038,7 @@ static void stage_gain_adjust(const lc3o_enc* e, const chan_t* s, int* gg, int g
         else if (*gg == 254 || nBits < target + delta) *gg = *gg + 1;
         else *gg = *gg + 2;
         *gg = IMAX(*gg, gg_min - off);
-        *gain = m_powf(10, (float)(*gg + off) / 28);
+        *gain = powf(10, (float)(*gg + off) / 28);       /* product: host-side libm table */
         *change = 1;
     }
 }
