@@ -211,6 +211,11 @@ static void build_plan(const geom_t* g, lc3d_plan* p)
     p->c_1em5_a = powf(10.0, -5.0); p->c_1em5_b = powf(10, -5); p->c_1em4 = powf(10.0, -40.0 / 10.0);
     p->c_2m32 = powf(2.0, -32.0); p->c_2m31 = powf(2, -31); p->c_2m24 = powf(2, -24); p->c_2p15 = powf(2, 15); p->c_2p100 = powf(2, 100);
     p->c_sqrt2 = sqrtf(2);
+    {   /* float thresholds equivalent to the reference's double comparisons against float operands */
+        const double t7 = (7.0) * (28.0 / 20.0), t50 = (50.0) * (28.0 / 20.0);
+        float f = (float)t7; if ((double)f < t7) f = nextafterf(f, INFINITY); p->c_thr7_up = f;
+        f = (float)t50; if ((double)f > t50) f = nextafterf(f, -INFINITY); p->c_thr50_dn = f;
+    }
     memset(p->band_of_bin, 255, sizeof p->band_of_bin);
     const uint16_t* be = &lc3t_band_pool[g->tab->band_off];
     for (int b = 0; b < g->nbands; b++) for (int j = be[b]; j < be[b + 1] && j < LC3D_MAX_N; j++) p->band_of_bin[j] = (uint8_t)b;
@@ -220,7 +225,7 @@ static void build_plan(const geom_t* g, lc3d_plan* p)
 static void init_state(float* st)                                         /* zeroed EncSetup + olpa_mem_pitch = 17 (R/setup_enc_lc3.c:178) */
 {
     memset(st, 0, sizeof(float) * LC3D_STATE_WORDS);
-    ((int*)(st + LC3D_ST_SCAL))[LC3D_S_OLPA_PITCH] = 17;
+    ((int*)st)[LC3D_S_OLPA_PITCH_WORD] = 17;
 }
 
 /* ------------------------------------------------------------------------------------------------ */

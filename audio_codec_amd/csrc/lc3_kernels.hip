@@ -2,16 +2,21 @@
  *
  * One 64-lane wavefront encodes one channel-stream and walks its frames in time order; the spectrum,
  * the 12.8 kHz / 6.4 kHz pitch-analysis histories, the quantised spectrum, the entropy-coder symbol
- * list and the output frame all live in that wave's LDS slice.  PCM is read from HBM with coalesced
- * loads, bytes are written back coalesced; cross-frame state is read once per launch and written once.
- * No MFMA (nothing here is a dense contraction), no collectives.
+ * list, all cross-frame scalars and the output frame live in that wave's LDS slice.  PCM is read from HBM
+ * with coalesced loads, bytes are written back coalesced; cross-frame state is read once per launch and
+ * written once.  No MFMA (nothing here is a dense contraction), no collectives.
  *
  * Numerics contract: every floating-point expression keeps the ETSI reference's evaluation order and
  * C promotions (R = LC3plus_ETSI_src_v17171_20200723/src/floating_point, cited per stage), compiled with
  * -ffp-contract=off, so that decisions (argmax, thresholds, quantisation) match the reference bit for bit.
  * Independent serial sums (autocorrelation lags, FIR taps, band energies ...) are mapped one sum per lane,
- * which keeps the reference's summation order AND fills the wave.  Run-time libm calls of the reference
- * (log2f, log10f, powf) are evaluated as (float)f((double)x) with the device's double libm.
+ * which keeps the reference's summation order AND fills the wave.  Strictly serial chains (biquad, normalised
+ * correlations, bisection, range coder) run on wave-uniform values: operands are fetched from lane registers
+ * with v_readlane (no LDS round trip) and integer state lives in scalar registers.  Run-time libm calls of the
+ * reference (log2f, log10f, powf) are evaluated as (float)f((double)x) with the device's double libm.
+ *
+ * Stage functions are deliberately NOT inlined: each gets its own register allocation, which keeps the kernel
+ * at <= 3 waves' worth of VGPRs per SIMD instead of the union of all live ranges.
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -24,29 +29,47 @@
 #include "lc3_shim.h"
 
 #define MAXN LC3D_MAX_N
+#define MEMCAP 300              /* MDCT overlap memory: N - la_zeros <= 300 for every N <= 480 */
 #define WAVE 64
 #define LSYNC() __syncthreads()
+#define STAGE __device__ __attribute__((noinline))
+
+/* Diagnostic build only (-DLC3_STAGE_TIMING, tools/stage_timing.py): per-stage wave-latency accounting with s_memtime.
+ * The product library is built without it; no stamp executes there. */
+#ifdef LC3_STAGE_TIMING
+#define NSTAGE 24
+#define TICK(id) do { long long now_ = clock64(); if (lane == 0) L.tacc[id] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define TICK(id) do { } while (0)
+#endif
 
 /* ------------------------------------------------------------------------------------------------ */
-/* LDS slice of one wave                                                                             */
+/* LDS slice of one wave (~12.8 KB -> 12 waves per CU)                                                */
 /* ------------------------------------------------------------------------------------------------ */
 struct __attribute__((aligned(16))) WaveLds {
-    float xbuf[2 * MAXN];   /* previous frame right-aligned in [0,MAXN), current frame in [MAXN, MAXN+N) */
-    float za[MAXN];         /* DFT in  / scratch */
-    float zb[MAXN];         /* DFT out / scratch */
-    float spec[MAXN];       /* MDCT spectrum, shaped / TNS-filtered in place */
-    float h12[384];         /* HP-filtered 12.8 kHz stream, newest sample at [383] */
-    float h6[196];          /* 6.4 kHz stream, newest at [193] */
-    float sm[704];          /* small vectors, see SM_* */
-    int   xq[MAXN];
-    uint32_t cd[MAXN / 2];  /* per 2-tuple: ctx | (maxlev+1)<<10 | sym<<16 */
-    uint32_t cf[MAXN / 2];  /* per 2-tuple: cumfreq | symfreq<<16 of the final symbol */
-    int   isc[64];          /* integer scalars passed between phases */
-    uint8_t bytes[416];
-    uint8_t res[640];
+    float xbuf[MEMCAP + MAXN];  /* [MDCT/resampler memory right-aligned in 0..MEMCAP | current frame]; after the time-domain
+                                   stages and the MDCT the frame half is reused for the quantised spectrum (xq) */
+    float A[MAXN];              /* scratch, then the MDCT spectrum (shaped / TNS-filtered in place) */
+    float B[MAXN];              /* scratch */
+    float h12[384];             /* HP-filtered 12.8 kHz stream, newest sample at [383] */
+    float h6[196];              /* 6.4 kHz stream, newest at [193] */
+    float sm[704];              /* small vectors (SM_*); from quantisation on: cd[240] | cf[240] | zero-line list / residual bits */
+    float fsc[16];              /* float scalars: cross-frame state + values passed between stages */
+    int   isc[80];              /* integer scalars */
+    uint8_t bytes[416];         /* the output frame */
+#ifdef LC3_STAGE_TIMING
+    long long tacc[NSTAGE];
+#endif
 };
+#define XCUR(L) (&(L).xbuf[MEMCAP])
+#define XQ(L)   ((int*)&(L).xbuf[MEMCAP])
+#define SPEC(L) ((L).A)
+#define CD(L)   ((uint32_t*)&(L).sm[0])      /* per 2-tuple: ctx | (maxlev+1)<<10 | sym<<16 */
+#define CF(L)   ((uint32_t*)&(L).sm[240])    /* per 2-tuple: cumfreq | symfreq<<16 of the final symbol */
+#define RESB(L) ((uint8_t*)&(L).sm[480])     /* 640 bytes: residual bits / LSB-mode list (bit-packed, LSB first) */
+#define ZKL(L)  ((uint16_t*)&(L).sm[480])    /* noise factor: 1-based indices of the zero lines */
 
-/* sm[] map (floats) */
+/* sm[] map (floats) before quantisation */
 #define SM_ENER   0     /* 64  band energies (modified in place by SNS) */
 #define SM_GI     64    /* 64  interpolated SNS gains */
 #define SM_SCF    128   /* 16 */
@@ -54,14 +77,17 @@ struct __attribute__((aligned(16))) WaveLds {
 #define SM_TGT    160   /* 16 pvq target (dct domain) */
 #define SM_TGTP   176   /* 16 pvq target pre */
 #define SM_ST1    192   /* 16 */
-#define SM_VEC    208   /* 6*16 = 96: candidate vectors / idct outputs */
-#define SM_PVQ    304   /* 4 * 52 per-search scratch: xabs[16], y[17] (int), ynorm[16] -> 208 */
-#define PVQ_STRIDE 52
-#define SM_MISC   512   /* 192: R0 (98), cor, tns r[], ... */
+#define SM_VEC    208   /* 6*16 = 96: candidate vectors */
+#define SM_PVQ    304   /* 4 searches x (y[16] int, ynorm[16]) = 128 */
+#define SM_MISC   512   /* 192: R0 (98), cor, tns r[], idct in/out ... */
 
+/* fsc[] map */
+enum { F_HP0 = 0, F_HP1, F_LTPF_NC1, F_LTPF_NC2, F_LTPF_PITCH, F_ATT_M0, F_ATT_M1, F_ATT_ACC, F_TBITS_OFF, F_NC, F_GAIN };
 /* isc[] map */
-enum { I_T0 = 0, I_LTPF0, I_LTPF1, I_LTPF2, I_LTPF_BITS, I_BW, I_SCF0, I_SCF1, I_SCF2, I_SCF3, I_SCF4, I_SCF5, I_SCF6,
-       I_TNS_NF, I_TNS_ORD0, I_TNS_ORD1, I_TNS_BITS, I_TNS_IDX0 /* 16 entries */, I_NEXT = I_TNS_IDX0 + 16 };
+enum { I_OLPA_PITCH = 0, I_LTPF_ON, I_ATT_POS, I_ATT_FLAG, I_MEM_TARGET, I_MEM_SPEC,
+       I_T0, I_LTPF0, I_LTPF1, I_LTPF2, I_LTPF_BITS, I_BW, I_SCF0, I_SCF1, I_SCF2, I_SCF3, I_SCF4, I_SCF5, I_SCF6,
+       I_TNS_NF, I_TNS_ORD0, I_TNS_ORD1, I_TNS_BITS, I_TNS_IDX0 /* 16 entries */, I_GG = I_TNS_IDX0 + 16, I_GGMIN, I_NBITS, I_NBITS2,
+       I_LASTNZ, I_LSB, I_CHANGE, I_FACNS, I_NRES, I_BP_SIDE, I_MASK_SIDE, I_COUNT };
 
 /* ------------------------------------------------------------------------------------------------ */
 /* small helpers                                                                                     */
@@ -73,6 +99,8 @@ __device__ __forceinline__ float mul_d(float a, double c) { return (float)((doub
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
 __device__ __forceinline__ int ilog2(unsigned v) { return 31 - __clz((int)v); }
+/* wave-uniform value -> scalar register (lets the compiler use SALU + scalar branches for serial code) */
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 /* floor(log2f((float)v)) as glibc evaluates it: log2f rounds to an integer for the few v just below 2^b
  * (SURVEY 9): 2^21-1, 2^22-{1,2}, 2^23-{1..5}, 2^24-{1..11}. */
@@ -254,148 +282,89 @@ __device__ __forceinline__ void dft5(float* v)
 }
 
 /* ------------------------------------------------------------------------------------------------ */
-/* frame context                                                                                     */
-/* ------------------------------------------------------------------------------------------------ */
-struct Scal {   /* wave-uniform cross-frame scalars (R/setup_enc_lc3.h:18-52) kept in registers */
-    float hp0, hp1;
-    int olpa_pitch;
-    float ltpf_nc1, ltpf_nc2, ltpf_pitch; int ltpf_on;
-    float att_m0, att_m1, att_acc; int att_pos, att_flag;
-    float tbits_off; int mem_target, mem_spec;
-};
-
-/* ---- MDCT: R/mdct.c:103-124 + R/dct4.c:75-95 + R/fft/fft_240_480.h:16-88 / R/fft/fft_generic.h:634-699 ---- */
-__device__ void st_mdct(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
+__device__ __forceinline__ float unif(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ float rl_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ double rl_d(double v, int l)
 {
-    const int N = P->N, h = N >> 1, la = P->la;
-    const float* w = &lc3t_win_pool[P->win_off];
-    const float* t = &L.xbuf[MAXN - N + la];       /* t[j], j < 2N-la ; zero beyond */
-    const int lim = 2 * N - la;
-    for (int i = lane; i < h; i += WAVE) {
-        int j0 = 3 * h - i - 1, j1 = 3 * h + i, j2 = i, j3 = 2 * h - i - 1;
-        float a0 = (j0 < lim ? t[j0] : 0.0f) * w[j0];
-        float a1 = (j1 < lim ? t[j1] : 0.0f) * w[j1];
-        float a2 = t[j2] * w[j2];
-        float a3 = t[j3] * w[j3];
-        L.zb[i] = -a0 - a1;
-        L.zb[h + i] = a2 - a3;
-    }
-    LSYNC();
-    for (int i = lane; i < h; i += WAVE) {          /* pre-twiddle R/dct4.c:84-86 */
-        float ar = L.zb[2 * i], ai = L.zb[N - 2 * i - 1], br = P->tw1[2 * i], bi = P->tw1[2 * i + 1];
-        L.za[2 * i] = ar * br - ai * bi;
-        L.za[2 * i + 1] = ai * br + ar * bi;
-    }
-    LSYNC();
-    if (h == 240) {
-        if (lane < 15) {
-            float v[32];
-#pragma unroll
-            for (int l = 0; l < 16; l++) { int s = (225 * l + 16 * lane) % 240; v[2 * l] = L.za[2 * s]; v[2 * l + 1] = L.za[2 * s + 1]; }
-            dft16(v);
-#pragma unroll
-            for (int l = 0; l < 16; l++) { int s = (225 * l + 16 * lane) % 240; L.za[2 * s] = v[2 * l]; L.za[2 * s + 1] = v[2 * l + 1]; }
-        }
-        LSYNC();
-        if (lane < 16) {
-            float v[30];
-#pragma unroll
-            for (int l = 0; l < 15; l++) { int s = (225 * lane + 16 * l) % 240; v[2 * l] = L.za[2 * s]; v[2 * l + 1] = L.za[2 * s + 1]; }
-            dft15(v);
-#pragma unroll
-            for (int l = 0; l < 15; l++) { int d = (15 * lane + 16 * l) % 240; L.zb[2 * d] = v[2 * l]; L.zb[2 * d + 1] = v[2 * l + 1]; }
-        }
-        LSYNC();
-    } else {   /* h == 120: prime-factor 8 x 3 x 5, index maps precomputed on the host (lc3_host.c: pfa_plan) */
-        const uint8_t* m1 = P->pfa_src; const uint8_t* m2 = P->pfa_src + 120; const uint8_t* m3 = P->pfa_src + 240;
-        if (lane < 15) {
-            float v[16];
-#pragma unroll
-            for (int j = 0; j < 8; j++) { int s = m1[lane * 8 + j]; v[2 * j] = L.za[2 * s]; v[2 * j + 1] = L.za[2 * s + 1]; }
-            dft8(v);
-#pragma unroll
-            for (int j = 0; j < 8; j++) { int d = lane * 8 + j; L.zb[2 * d] = v[2 * j]; L.zb[2 * d + 1] = v[2 * j + 1]; }
-        }
-        LSYNC();
-        if (lane < 40) {
-            float v[6];
-#pragma unroll
-            for (int j = 0; j < 3; j++) { int s = m2[lane * 3 + j]; v[2 * j] = L.zb[2 * s]; v[2 * j + 1] = L.zb[2 * s + 1]; }
-            dft3(v);
-#pragma unroll
-            for (int j = 0; j < 3; j++) { int d = lane * 3 + j; L.za[2 * d] = v[2 * j]; L.za[2 * d + 1] = v[2 * j + 1]; }
-        }
-        LSYNC();
-        float v[10];
-        if (lane < 24) {
-#pragma unroll
-            for (int j = 0; j < 5; j++) { int s = m3[lane * 5 + j]; v[2 * j] = L.za[2 * s]; v[2 * j + 1] = L.za[2 * s + 1]; }
-            dft5(v);
-        }
-        LSYNC();
-        if (lane < 24) {
-#pragma unroll
-            for (int j = 0; j < 5; j++) { int d = P->pfa_dst[lane * 5 + j]; L.zb[2 * d] = v[2 * j]; L.zb[2 * d + 1] = v[2 * j + 1]; }
-        }
-        LSYNC();
-    }
-    const float norm = P->dct4_norm;
-    for (int i = lane; i < h; i += WAVE) {          /* post-twiddle R/dct4.c:90-94 */
-        float ar = L.zb[2 * i], ai = L.zb[2 * i + 1], br = P->tw2[2 * i], bi = P->tw2[2 * i + 1];
-        float tr = ar * br - ai * bi, ti = ai * br + ar * bi;
-        L.spec[2 * i] = tr * norm;
-        L.spec[N - 2 * i - 1] = -ti * norm;
-    }
-    LSYNC();
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
 
+/* ------------------------------------------------------------------------------------------------ */
+/* time-domain analysis                                                                              */
+/* ------------------------------------------------------------------------------------------------ */
+
 /* ---- 12.8 kHz resampler + 50 Hz high-pass: R/resamp12k8.c:13-84.  Appends len12 samples to h12. ---- */
-__device__ void st_resample(const lc3d_plan* __restrict__ P, WaveLds& L, Scal& S, int lane)
+STAGE void st_resample(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
 {
     const int mlen = P->rs_mem_in_len, stride = P->rs_stride, n12 = P->n12, len12 = P->len12;
     const float sf = P->rs_scale;
-    const float* buf = &L.xbuf[MAXN - mlen];        /* [mem_in | x] */
-    float* down = L.za;                             /* scratch: n12 floats */
-    for (int n = lane; n < n12; n += WAVE) {
-        int i = 15 * n, start = (-i) % stride;
-        if (start < 0) start += stride;
-        float mac = 0;
-        for (int j = start; j < 240; j += stride) mac += buf[(i + j) / stride] * sf * lc3t_rs_lp[240 - j - 1];
-        down[n] = mac;
+    const float* buf = &L.xbuf[MEMCAP - mlen];      /* [mem_in | x] */
+    float d[2] = {0, 0};
+#pragma unroll
+    for (int h = 0; h < 2; h++) {                   /* one polyphase FIR output per lane and half: taps in the reference's order */
+        const int n = lane + 64 * h;
+        if (n < n12) {
+            const int i = 15 * n, r = i % stride, start = r ? stride - r : 0;
+            const float* bp = buf + (i + start) / stride; const float* fp = &lc3t_rs_lp[239 - start];
+            const int cnt = (240 - start + stride - 1) / stride;
+            float mac = 0;
+#pragma unroll 12
+            for (int m = 0; m < cnt; m++) mac += bp[m] * sf * fp[-m * stride];
+            d[h] = mac;
+        }
     }
-    /* shift the 12.8 kHz history while the FIR results settle */
+    /* biquad in double, strictly serial (R/resamp12k8.c:60-74): the x-only products are formed per lane, the recurrence reads
+     * them with readlane, the outputs are dropped back into their lane */
+    const double b0 = lc3t_hp50_b[0], b1 = lc3t_hp50_b[1], b2 = lc3t_hp50_b[2], a1 = lc3t_hp50_a[1], a2 = lc3t_hp50_a[2];
+    double u11 = (double)L.fsc[F_HP0], u21 = (double)L.fsc[F_HP1];
+    float y[2] = {0, 0};
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const double x = (double)d[h], q0 = b0 * x, q1 = b1 * x, q2 = b2 * x;
+        const int cnt = imin(len12 - 64 * h, 64);
+        for (int i = 0; i < cnt; i++) {
+            const double y1 = (rl_d(q0, i) + u11);
+            const double u1 = (rl_d(q1, i) + u21) - a1 * y1;
+            const double u2 = rl_d(q2, i) - a2 * y1;
+            u11 = u1; u21 = u2;
+            y[h] = (lane == i) ? (float)y1 : y[h];
+        }
+    }
     float keep[6];
 #pragma unroll
-    for (int k = 0; k < 6; k++) { int i = lane + 64 * k; keep[k] = (i + len12 < 384) ? L.h12[i + len12] : 0.0f; }
+    for (int k = 0; k < 6; k++) { const int i = lane + 64 * k; keep[k] = (i + len12 < 384) ? L.h12[i + len12] : 0.0f; }
     LSYNC();
 #pragma unroll
-    for (int k = 0; k < 6; k++) { int i = lane + 64 * k; if (i + len12 < 384) L.h12[i] = keep[k]; }
-    /* biquad in double, strictly serial (uniform across lanes) */
-    double u11 = S.hp0, u21 = S.hp1;
-    const double b0 = lc3t_hp50_b[0], b1 = lc3t_hp50_b[1], b2 = lc3t_hp50_b[2], a1 = lc3t_hp50_a[1], a2 = lc3t_hp50_a[2];
-    for (int i = 0; i < len12; i++) {
-        double x = (double)down[i];
-        double y1 = (b0 * x + u11);
-        double u1 = (b1 * x + u21) - a1 * y1;
-        double u2 = b2 * x - a2 * y1;
-        u11 = u1; u21 = u2;
-        if (lane == 0) L.h12[384 - len12 + i] = (float)y1;
-    }
-    S.hp0 = (float)u11; S.hp1 = (float)u21;
+    for (int k = 0; k < 6; k++) { const int i = lane + 64 * k; if (i + len12 < 384) L.h12[i] = keep[k]; }
+    if (lane < len12) L.h12[384 - len12 + lane] = y[0];
+    if (lane + 64 < len12) L.h12[384 - len12 + 64 + lane] = y[1];
+    if (lane == 0) { L.fsc[F_HP0] = (float)u11; L.fsc[F_HP1] = (float)u21; }
     LSYNC();
 }
 
+/* normalised correlation at lag T over acf <= 64 samples (R/olpa.c:104-114): serial float sums fed by readlane */
+__device__ __forceinline__ float olpa_normcorr(const float* s6, int acf, int T, int lane, float eps)
+{
+    const float a = lane < acf ? s6[lane] : 0.0f, b = lane < acf ? s6[lane - T] : 0.0f;
+    const float p0 = a * b, p1 = b * b, p2 = a * a;
+    float s0 = 0, s1 = 0, s2 = 0;
+    for (int i = 0; i < acf; i++) { s0 += rl_f(p0, i); s1 += rl_f(p1, i); s2 += rl_f(p2, i); }
+    s1 = s1 * s2;
+    s1 = sqrtf(s1) + eps;
+    const float nc = s0 / s1;
+    return 0 > nc ? 0 : nc;
+}
+
 /* ---- open-loop pitch: R/olpa.c:52-143 ---- */
-__device__ void st_olpa(const lc3d_plan* __restrict__ P, WaveLds& L, Scal& S, int lane, int& T0_out, float& nc_out)
+STAGE void st_olpa(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
 {
     const int len = P->len12, len2 = len >> 1;
     int acf = len2, back = 0;
     if (P->dms == 25) { acf += 16; back = 16; }
-    /* decimate: d6[j] = sum_k dec[k] * in12[4+2j-k], in12[i] = h12[384 - len - 27 + i] */
     float nd = 0;
-    if (lane < len2) {
+    if (lane < len2) {                              /* 2:1 decimation (filter_olpa R/olpa.c:16-31) */
         const float* in12 = &L.h12[384 - len - 27];
-        int i = 4 + 2 * lane;
+        const int i = 4 + 2 * lane;
         float sum = 0;
 #pragma unroll
         for (int k = 0; k < 5; k++) sum += lc3t_olpa_dec[k] * in12[i - k];
@@ -403,90 +372,95 @@ __device__ void st_olpa(const lc3d_plan* __restrict__ P, WaveLds& L, Scal& S, in
     }
     float keep[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) { int i = lane + 64 * k; keep[k] = (i + len2 < 194) ? L.h6[i + len2] : 0.0f; }
+    for (int k = 0; k < 4; k++) { const int i = lane + 64 * k; keep[k] = (i + len2 < 194) ? L.h6[i + len2] : 0.0f; }
     LSYNC();
 #pragma unroll
-    for (int k = 0; k < 4; k++) { int i = lane + 64 * k; if (i + len2 < 194) L.h6[i] = keep[k]; }
+    for (int k = 0; k < 4; k++) { const int i = lane + 64 * k; if (i + len2 < 194) L.h6[i] = keep[k]; }
     if (lane < len2) L.h6[194 - len2 + lane] = nd;
     LSYNC();
     const float* s6 = &L.h6[194 - len2 - back];
-    float* R0 = &L.sm[SM_MISC];        /* 98 unweighted */
-    float best = -INFINITY; int besti = 0x7fffffff;
-    for (int q = lane; q < 98; q += WAVE) {
-        int lag = 17 + q;
-        float sum = 0;
-        for (int j = 0; j < acf; j++) sum += s6[j] * s6[j - lag];
-        R0[q] = sum;
-        float wv = sum * lc3t_olpa_w[q];
-        if (wv > best) { best = wv; besti = q; }       /* lane-local: lower q first */
-    }
+    float* R0 = &L.sm[SM_MISC];                     /* 98 unweighted autocorrelations */
+    const bool two = lane < 34;
+    const float* q0 = s6 - (17 + lane); const float* q1 = s6 - (two ? 81 + lane : 17 + lane);
+    float r0 = 0, r1 = 0;
+#pragma unroll 8
+    for (int j = 0; j < acf; j++) { const float a = s6[j]; r0 += a * q0[j]; r1 += a * q1[j]; }
+    R0[lane] = r0;
+    if (two) R0[64 + lane] = r1;
+    float best = r0 * lc3t_olpa_w[lane]; int besti = lane;
+    if (two) { const float w1 = r1 * lc3t_olpa_w[64 + lane]; if (w1 > best) { best = w1; besti = 64 + lane; } }
     wave_argmax_first(best, besti, 64);
-    int T0 = besti + 17;
+    int T0 = uni(besti) + 17;
     LSYNC();
-    float s0 = 0, s1 = 0, s2 = 0;
-    for (int i = 0; i < acf; i++) { float a = s6[i], b = s6[i - T0]; s0 += a * b; s1 += b * b; s2 += a * a; }
-    s1 = s1 * s2;
-    s1 = sqrtf(s1) + P->c_1em5_a;
-    float nc = s0 / s1;
-    nc = 0 > nc ? 0 : nc;
-    int lo = imax(17, S.olpa_pitch - 4), hi = imin(114, S.olpa_pitch + 4);
-    int bi = 0; float bm = R0[lo - 17];
-    for (int i = 0; i < hi - lo + 1; i++) { float v = R0[lo - 17 + i]; if (v > bm) { bm = v; bi = i; } }
-    int T02 = bi + lo;
+    float nc = olpa_normcorr(s6, acf, T0, lane, P->c_1em5_a);
+    const int old = uni(L.isc[I_OLPA_PITCH]);
+    const int lo = imax(17, old - 4), hi = imin(114, old + 4), cnt = hi - lo + 1;
+    float v = (lane & 15) < cnt ? R0[lo - 17 + (lane & 15)] : -INFINITY; int vi = lane & 15;
+    wave_argmax_first(v, vi, 16);
+    const int T02 = uni(vi) + lo;
     if (T02 != T0) {
-        s0 = s1 = s2 = 0;
-        for (int i = 0; i < acf; i++) { float a = s6[i], b = s6[i - T02]; s0 += a * b; s1 += b * b; s2 += a * a; }
-        s1 = s1 * s2;
-        s1 = sqrtf(s1) + P->c_1em5_a;
-        float nc2 = s0 / s1;
-        nc2 = 0 > nc2 ? 0 : nc2;
+        const float nc2 = olpa_normcorr(s6, acf, T02, lane, P->c_1em5_a);
         if ((double)nc2 > ((double)nc * 0.85)) { T0 = T02; nc = nc2; }
     }
-    S.olpa_pitch = T0;
-    T0_out = (int)(T0 * 2.0);
-    nc_out = nc;
+    if (lane == 0) { L.isc[I_OLPA_PITCH] = T0; L.isc[I_T0] = (int)(T0 * 2.0); L.fsc[F_NC] = nc; }
     LSYNC();
 }
 
 /* ---- LTPF parameter coder: R/ltpf_coder.c:34-263 ---- */
-__device__ void st_ltpf(const lc3d_plan* __restrict__ P, const lc3d_chan& C, WaveLds& L, Scal& S, int lane, int pitch_ol, float ol_nc,
-                        int* param, int& bits)
+STAGE void st_ltpf(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ C, WaveLds& L, int lane)
 {
     const int len = P->len12;                 /* N of the reference = xLen - 1 */
     const float* x = &L.h12[384 - len - 24];
+    const int pitch_ol = uni(L.isc[I_T0]); const float ol_nc = unif(L.fsc[F_NC]);
+    const int mem_on = uni(L.isc[I_LTPF_ON]);
+    const float nc1 = unif(L.fsc[F_LTPF_NC1]), nc2m = unif(L.fsc[F_LTPF_NC2]), mem_pitch = unif(L.fsc[F_LTPF_PITCH]);
     int active = 0, pitch_index = 0, gain = 0;
     float norm_corr = 0, pitch = 0;
     if ((double)ol_nc > 0.6) {
-        int t0_min = imax(pitch_ol - 4, 32), t0_max = imin(pitch_ol + 4, 228), acf = len;
+        const int t0_min = imax(pitch_ol - 4, 32), t0_max = imin(pitch_ol + 4, 228);
+        int acf = len;
         if (P->dms == 25) { acf = 2 * len; x = x - len; }
         const int t_min = t0_min - 4, t_max = t0_max + 4, nl = t_max - t_min + 1;
         float sum1 = 0, sum2 = 0;
-        for (int j = 0; j < acf; j++) { float a = x[j], b = x[j - t_min]; sum1 += a * a; sum2 += b * b; }
+        {   /* R/ltpf_coder.c:74-78: two serial sums over acf <= 128 terms, products per lane */
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int j = lane + 64 * h;
+                const float a = j < acf ? x[j] : 0.0f, b = j < acf ? x[j - t_min] : 0.0f;
+                const float pa = a * a, pb = b * b;
+                const int cnt = imin(acf - 64 * h, 64);
+                for (int i = 0; i < cnt; i++) { sum1 += rl_f(pa, i); sum2 += rl_f(pb, i); }
+            }
+        }
         float* cor = &L.sm[SM_MISC];           /* up to 17 */
         float* cor_int = &L.sm[SM_MISC + 32];  /* up to 36 */
         if (lane < nl) {
             const int lag = t_min + lane;
+            const float* xl = x - lag;
             float sum = 0;
-            for (int j = 0; j < acf; j++) sum += x[j] * x[j - lag];
+#pragma unroll 8
+            for (int j = 0; j < acf; j++) sum += x[j] * xl[j];
             float s2 = sum2;
             for (int k = t_min + 1; k <= lag; k++) s2 = s2 + x[-k] * x[-k] - x[acf - 1 - (k - 1)] * x[acf - 1 - (k - 1)];
-            float sum3 = sqrtf(sum1 * s2) + P->c_1em5_b;
+            const float sum3 = sqrtf(sum1 * s2) + P->c_1em5_b;
             float nc = sum / sum3;
             nc = 0 > nc ? 0 : nc;
             cor[lane] = nc;
         }
         LSYNC();
-        int tsel = 0; { float m = 0; for (int i = 0; i < t_max - t_min - 8 + 1; i++) { float v = cor[4 + i]; if (v > m) { m = v; tsel = i; } } }
+        int tsel;
+        { float v = lane < 16 && lane < t_max - t_min - 8 + 1 ? cor[4 + lane] : -INFINITY; int vi = lane & 15; wave_argmax_first(v, vi, 16);
+          tsel = unif(v) > 0 ? uni(vi) : 0; }
         const int t1 = tsel + t0_min;
         int pitch_int, pitch_fr;
         if (t1 >= 157) { pitch_int = t1; pitch_fr = 0; }
         else {
             const int nint = 4 * (t0_max - t0_min + 1);
             if (lane < nint) {
-                /* cor_up is cor zero-stuffed by 4; zero taps add +-0 to a non-negative-zero accumulator: skipped */
+                /* cor_up is cor zero-stuffed by 4; its zero taps only add +-0 to the accumulator: skipped */
                 float sum = 0;
                 for (int k = (4 - (lane & 3)) & 3; k < 32; k += 4) {
-                    int m = (lane + k) >> 2;
+                    const int m = (lane + k) >> 2;
                     if (m <= t_max - t_min) sum += cor[m] * lc3t_ltpf_int4[k];
                 }
                 cor_int[lane] = sum;
@@ -495,7 +469,9 @@ __device__ void st_ltpf(const lc3d_plan* __restrict__ P, const lc3d_chan& C, Wav
             const int step = t1 >= 127 ? 2 : 1;
             const int mid = 4 * (t1 - t0_min) + 1, up = 4 - step, down = t1 == t0_min ? 0 : 4 - step;
             const int cnt = ((mid + up) - (mid - down)) / step + 1;
-            int ksel = 0; { float m = 0; for (int q = 0; q < cnt; q++) { float v = cor_int[mid - down - 1 + q * step]; if (v > m) { m = v; ksel = q; } } }
+            int ksel;
+            { float v = (lane & 15) < cnt ? cor_int[mid - down - 1 + (lane & 15) * step] : -INFINITY; int vi = lane & 15; wave_argmax_first(v, vi, 16);
+              ksel = unif(v) > 0 ? uni(vi) : 0; }
             pitch_fr = ksel * step - down;
             if (pitch_fr >= 0) pitch_int = t1; else { pitch_int = t1 - 1; pitch_fr = 4 + pitch_fr; }
         }
@@ -504,40 +480,47 @@ __device__ void st_ltpf(const lc3d_plan* __restrict__ P, const lc3d_chan& C, Wav
         else pitch_index = pitch_int - 157 + 380 + 60;
         pitch = (float)((double)(float)pitch_int + (double)(float)pitch_fr / 4.0);
         const float* f0 = &lc3t_ltpf_frac[0]; const float* fp = &lc3t_ltpf_frac[4 * pitch_fr];
-        float* cur = L.za; float* pred = L.zb;
-        for (int n = lane; n < acf; n += WAVE) {
-            cur[n] = x[n + 1] * f0[0] + x[n] * f0[1] + x[n - 1] * f0[2];
-            pred[n] = x[n - pitch_int + 1] * fp[0] + x[n - pitch_int] * fp[1] + x[n - pitch_int - 1] * fp[2] + x[n - pitch_int - 2] * fp[3];
-        }
-        LSYNC();
         float a = 0, b = 0, c = 0;
-        for (int i = 0; i < acf; i++) { float cu = cur[i], pr = pred[i]; a += cu * pr; b += cu * cu; c += pr * pr; }
+#pragma unroll
+        for (int h = 0; h < 2; h++) {               /* R/ltpf_coder.c:190-216 */
+            const int n = lane + 64 * h;
+            float cu = 0, pr = 0;
+            if (n < acf) {
+                cu = x[n + 1] * f0[0] + x[n] * f0[1] + x[n - 1] * f0[2];
+                pr = x[n - pitch_int + 1] * fp[0] + x[n - pitch_int] * fp[1] + x[n - pitch_int - 1] * fp[2] + x[n - pitch_int - 2] * fp[3];
+            }
+            const float pa = cu * pr, pb = cu * cu, pc = pr * pr;
+            const int cnt = imin(acf - 64 * h, 64);
+            for (int i = 0; i < cnt; i++) { a += rl_f(pa, i); b += rl_f(pb, i); c += rl_f(pc, i); }
+        }
         b = sqrtf(b * c) + P->c_1em5_b;
         norm_corr = a / b;
-        { float lo = -1 > norm_corr ? -1 : norm_corr; norm_corr = 1 < lo ? 1 : lo; }
+        { const float lo = -1 > norm_corr ? -1 : norm_corr; norm_corr = 1 < lo ? 1 : lo; }
         if (norm_corr < 0) norm_corr = 0;
-        if (C.ltpf_enable == 1) {
-            if ((S.ltpf_on == 0 && (P->dms == 100 || (double)S.ltpf_nc2 > 0.94) && (double)S.ltpf_nc1 > 0.94 && (double)norm_corr > 0.94) ||
-                (S.ltpf_on == 1 && (double)norm_corr > 0.9) ||
-                (S.ltpf_on == 1 && fabsf(pitch - S.ltpf_pitch) < 2 && (double)(norm_corr - S.ltpf_nc1) > -0.1 && (double)norm_corr > 0.84))
+        if (C->ltpf_enable == 1) {
+            if ((mem_on == 0 && (P->dms == 100 || (double)nc2m > 0.94) && (double)nc1 > 0.94 && (double)norm_corr > 0.94) ||
+                (mem_on == 1 && (double)norm_corr > 0.9) ||
+                (mem_on == 1 && fabsf(pitch - mem_pitch) < 2 && (double)(norm_corr - nc1) > -0.1 && (double)norm_corr > 0.84))
                 active = 1;
         }
         gain = 4;
-        LSYNC();
     } else { gain = 0; norm_corr = ol_nc; pitch = 0; }
-    if (gain > 0) { param[0] = 1; param[1] = active; param[2] = pitch_index; bits = 11; }
-    else { param[0] = param[1] = param[2] = 0; bits = 1; }
-    if (P->dms < 100) S.ltpf_nc2 = S.ltpf_nc1;
-    S.ltpf_nc1 = norm_corr; S.ltpf_on = active; S.ltpf_pitch = pitch;
+    LSYNC();
+    if (lane == 0) {
+        if (gain > 0) { L.isc[I_LTPF0] = 1; L.isc[I_LTPF1] = active; L.isc[I_LTPF2] = pitch_index; L.isc[I_LTPF_BITS] = 11; }
+        else { L.isc[I_LTPF0] = 0; L.isc[I_LTPF1] = 0; L.isc[I_LTPF2] = 0; L.isc[I_LTPF_BITS] = 1; }
+        if (P->dms < 100) L.fsc[F_LTPF_NC2] = nc1;
+        L.fsc[F_LTPF_NC1] = norm_corr; L.isc[I_LTPF_ON] = active; L.fsc[F_LTPF_PITCH] = pitch;
+    }
+    LSYNC();
 }
 
 /* ---- attack detector: R/attack_detector.c:13-104 (only when attack_handling) ---- */
-__device__ void st_attack(const lc3d_plan* __restrict__ P, const lc3d_chan& C, WaveLds& L, Scal& S, int lane)
+STAGE void st_attack(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
 {
-    if (!C.attack_handling) return;
-    const int N = P->N, nb = P->att_nblocks, n16 = nb * 40;
-    const float* in = &L.xbuf[MAXN];
-    float* p = &L.za[2];
+    const int nb = P->att_nblocks, n16 = nb * 40;
+    const float* in = XCUR(L);
+    float* p = &L.A[2];
     float mval = 0;
     for (int j = lane; j < n16; j += WAVE) {
         float v;
@@ -548,10 +531,10 @@ __device__ void st_attack(const lc3d_plan* __restrict__ P, const lc3d_chan& C, W
         p[j] = v;
     }
     if (P->fs == 96000) mval = 1e-5f;
-    if (lane == 0) { p[-2] = S.att_m0; p[-1] = S.att_m1; }
+    if (lane == 0) { p[-2] = L.fsc[F_ATT_M0]; p[-1] = L.fsc[F_ATT_M1]; }
     LSYNC();
-    S.att_m0 = p[n16 - 2]; S.att_m1 = p[n16 - 1];
-    float* fs = L.zb;
+    const float nm0 = p[n16 - 2], nm1 = p[n16 - 1];
+    float* fs = L.B;
     for (int i = lane; i < 160; i += WAVE) {
         float t = 0;
         t = (float)((double)t + (double)p[i] * 0.375);
@@ -561,33 +544,131 @@ __device__ void st_attack(const lc3d_plan* __restrict__ P, const lc3d_chan& C, W
     }
     LSYNC();
     float e = 0;
-    if (lane < nb) { for (int k = 0; k < 40; k++) { float v = fs[k + lane * 40]; e += v * v; } }
+    if (lane < nb) { for (int k = 0; k < 40; k++) { const float v = fs[k + lane * 40]; e += v * v; } }
     int flag = 0, pos = -1;
-    float acc = S.att_acc;
+    float acc = unif(L.fsc[F_ATT_ACC]);
     for (int b = 0; b < nb; b++) {
-        float nrg = __shfl(e, b);
-        float t = (float)((double)nrg / 8.5);
+        const float nrg = rl_f(e, b);
+        const float t = (float)((double)nrg / 8.5);
         if (t > (acc > mval ? acc : mval)) { flag = 1; pos = b + 1; }
-        double q = 0.25 * (double)acc;
+        const double q = 0.25 * (double)acc;
         acc = (double)nrg > q ? nrg : (float)q;
     }
-    S.att_acc = acc;
-    if (S.att_pos > P->att_hang) flag = 1;
-    S.att_flag = flag;
-    S.att_pos = pos;
+    if (uni(L.isc[I_ATT_POS]) > P->att_hang) flag = 1;
     LSYNC();
-    (void)N;
+    if (lane == 0) { L.fsc[F_ATT_M0] = nm0; L.fsc[F_ATT_M1] = nm1; L.fsc[F_ATT_ACC] = acc; L.isc[I_ATT_FLAG] = flag; L.isc[I_ATT_POS] = pos; }
+    LSYNC();
 }
 
+/* ------------------------------------------------------------------------------------------------ */
+/* MDCT: R/mdct.c:103-124 + R/dct4.c:75-95 + R/fft/fft_240_480.h:16-88 / R/fft/fft_generic.h:634-699  */
+/* ------------------------------------------------------------------------------------------------ */
+STAGE void mdct_dft240_cols(WaveLds& L, int lane)   /* 15 transforms of length 16, in place in A */
+{
+    if (lane < 15) {
+        float v[32];
+#pragma unroll
+        for (int l = 0; l < 16; l++) { const int s = (225 * l + 16 * lane) % 240; v[2 * l] = L.A[2 * s]; v[2 * l + 1] = L.A[2 * s + 1]; }
+        dft16(v);
+#pragma unroll
+        for (int l = 0; l < 16; l++) { const int s = (225 * l + 16 * lane) % 240; L.A[2 * s] = v[2 * l]; L.A[2 * s + 1] = v[2 * l + 1]; }
+    }
+    LSYNC();
+}
+STAGE void mdct_dft240_rows(WaveLds& L, int lane)   /* 16 transforms of length 15, A -> B in natural order */
+{
+    if (lane < 16) {
+        float v[30];
+#pragma unroll
+        for (int l = 0; l < 15; l++) { const int s = (225 * lane + 16 * l) % 240; v[2 * l] = L.A[2 * s]; v[2 * l + 1] = L.A[2 * s + 1]; }
+        dft15(v);
+#pragma unroll
+        for (int l = 0; l < 15; l++) { const int d = (15 * lane + 16 * l) % 240; L.B[2 * d] = v[2 * l]; L.B[2 * d + 1] = v[2 * l + 1]; }
+    }
+    LSYNC();
+}
+STAGE void mdct_dft120(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)   /* 8 x 3 x 5 prime-factor DFT, A -> B */
+{
+    const uint8_t* m1 = P->pfa_src; const uint8_t* m2 = P->pfa_src + 120; const uint8_t* m3 = P->pfa_src + 240;
+    if (lane < 15) {
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 8; j++) { const int s = m1[lane * 8 + j]; v[2 * j] = L.A[2 * s]; v[2 * j + 1] = L.A[2 * s + 1]; }
+        dft8(v);
+#pragma unroll
+        for (int j = 0; j < 8; j++) { const int d = lane * 8 + j; L.B[2 * d] = v[2 * j]; L.B[2 * d + 1] = v[2 * j + 1]; }
+    }
+    LSYNC();
+    if (lane < 40) {
+        float v[6];
+#pragma unroll
+        for (int j = 0; j < 3; j++) { const int s = m2[lane * 3 + j]; v[2 * j] = L.B[2 * s]; v[2 * j + 1] = L.B[2 * s + 1]; }
+        dft3(v);
+#pragma unroll
+        for (int j = 0; j < 3; j++) { const int d = lane * 3 + j; L.A[2 * d] = v[2 * j]; L.A[2 * d + 1] = v[2 * j + 1]; }
+    }
+    LSYNC();
+    if (lane < 24) {
+        float v[10];
+#pragma unroll
+        for (int j = 0; j < 5; j++) { const int s = m3[lane * 5 + j]; v[2 * j] = L.A[2 * s]; v[2 * j + 1] = L.A[2 * s + 1]; }
+        dft5(v);
+#pragma unroll
+        for (int j = 0; j < 5; j++) { const int d = P->pfa_dst[lane * 5 + j]; L.B[2 * d] = v[2 * j]; L.B[2 * d + 1] = v[2 * j + 1]; }
+    }
+    LSYNC();
+}
+STAGE void st_mdct(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
+{
+    const int N = P->N, h = N >> 1, la = P->la;
+    const float* w = &lc3t_win_pool[P->win_off];
+    const float* t = &L.xbuf[MEMCAP - (N - la)];    /* t[j] = [memory | frame], j < 2N-la ; zero beyond */
+    const int lim = 2 * N - la;
+    for (int i = lane; i < h; i += WAVE) {
+        const int j0 = 3 * h - i - 1, j1 = 3 * h + i, j2 = i, j3 = 2 * h - i - 1;
+        const float a0 = (j0 < lim ? t[j0] : 0.0f) * w[j0];
+        const float a1 = (j1 < lim ? t[j1] : 0.0f) * w[j1];
+        const float a2 = t[j2] * w[j2];
+        const float a3 = t[j3] * w[j3];
+        L.B[i] = -a0 - a1;
+        L.B[h + i] = a2 - a3;
+    }
+    LSYNC();
+    for (int i = lane; i < h; i += WAVE) {          /* pre-twiddle R/dct4.c:84-86 */
+        const float ar = L.B[2 * i], ai = L.B[N - 2 * i - 1], br = P->tw1[2 * i], bi = P->tw1[2 * i + 1];
+        L.A[2 * i] = ar * br - ai * bi;
+        L.A[2 * i + 1] = ai * br + ar * bi;
+    }
+    LSYNC();
+    if (h == 240) { mdct_dft240_cols(L, lane); mdct_dft240_rows(L, lane); }
+    else mdct_dft120(P, L, lane);
+    const float norm = P->dct4_norm;
+    for (int i = lane; i < h; i += WAVE) {          /* post-twiddle R/dct4.c:90-94; the spectrum lands in A */
+        const float ar = L.B[2 * i], ai = L.B[2 * i + 1], br = P->tw2[2 * i], bi = P->tw2[2 * i + 1];
+        const float tr = ar * br - ai * bi, ti = ai * br + ar * bi;
+        L.A[2 * i] = tr * norm;
+        L.A[N - 2 * i - 1] = -ti * norm;
+    }
+    LSYNC();
+    /* the frame's tail becomes the next frame's MDCT / resampler memory; the frame half of xbuf is free afterwards */
+    const int ml = N - la;
+    for (int i = lane; i < ml; i += WAVE) L.xbuf[MEMCAP - ml + i] = L.xbuf[MEMCAP + N - ml + i];
+    LSYNC();
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* spectral shaping                                                                                  */
+/* ------------------------------------------------------------------------------------------------ */
+
 /* ---- per-band energy R/per_band_energy.c:13-30, bandwidth detector R/detect_cutoff_warped.c:13-83 ---- */
-__device__ int st_energy_bw(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
+STAGE void st_energy_bw(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
 {
     const uint16_t* be = &lc3t_band_pool[P->band_off];
     float* en = &L.sm[SM_ENER];
     if (lane < P->nbands) {
-        int a = be[lane], b = be[lane + 1];
+        const int a = be[lane], b = be[lane + 1];
         float sum = 0;
-        for (int j = a; j < b; j++) { float v = L.spec[j]; sum += v * v; }
+        for (int j = a; j < b; j++) { const float v = L.A[j]; sum += v * v; }
         en[lane] = sum / (float)(b - a);
     }
     LSYNC();
@@ -595,120 +676,116 @@ __device__ int st_energy_bw(const lc3d_plan* __restrict__ P, WaveLds& L, int lan
     if (P->fs_idx > 0 && P->hrmode == 0) {
         const int f = P->fs_idx;
         const uint8_t* st = &lc3t_bw_start[(P->bw_cls * 4 + f - 1) * 4]; const uint8_t* sp = &lc3t_bw_stop[(P->bw_cls * 4 + f - 1) * 4];
+        const float ev = en[lane];
         int counter = f;
         float sum = 0;
-        for (int i = st[counter - 1]; i <= sp[counter - 1]; i++) sum += en[i];
+        for (int i = st[counter - 1]; i <= sp[counter - 1]; i++) sum += rl_f(ev, i);
         float mean = sum / (float)(sp[counter - 1] - st[counter - 1] + 1);
         while (mean < (float)lc3t_bw_quiet_thr[counter - 1]) {
             counter--;
             if (counter == 0) break;
             sum = 0;
-            for (int i = st[counter - 1]; i <= sp[counter - 1]; i++) sum += en[i];
+            for (int i = st[counter - 1]; i <= sp[counter - 1]; i++) sum += rl_f(ev, i);
             mean = sum / (float)(sp[counter - 1] - st[counter - 1] + 1);
         }
         bw = counter;
         if (bw < f) {
-            float thr = (float)lc3t_bw_brick_thr[counter];
-            int stop = st[counter], dist = lc3t_bw_brick_dist[counter], brick = 0;
+            const float thr = (float)lc3t_bw_brick_thr[counter];
+            const int stop = st[counter], dist = lc3t_bw_brick_dist[counter];
+            int brick = 0;
             for (int i = stop; i >= stop - dist; i--) {
-                float ediff = (float)(10.0 * (double)m_log10f(en[i - dist + 1] + 1.1920928955078125e-07f) -
-                                      10.0 * (double)m_log10f(en[i + 1] + 1.1920928955078125e-07f));
+                const float ediff = (float)(10.0 * (double)m_log10f(rl_f(ev, i - dist + 1) + 1.1920928955078125e-07f) -
+                                            10.0 * (double)m_log10f(rl_f(ev, i + 1) + 1.1920928955078125e-07f));
                 if (ediff > thr) { brick = 1; break; }
             }
             if (!brick) bw = f;
         }
     }
-    return bw;
+    if (lane == 0) L.isc[I_BW] = bw;
+    LSYNC();
 }
 
 /* ---- SNS scale factors R/sns_compute_scf.c:13-176 ---- */
-__device__ void st_sns_scf(const lc3d_plan* __restrict__ P, WaveLds& L, int lane, int smooth)
+STAGE void st_sns_scf(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
 {
     float* x = &L.sm[SM_ENER];
-    float* tmp = &L.sm[SM_MISC];
+    const int smooth = uni(L.isc[I_ATT_FLAG]);
     int nb = P->nbands;
+    float c = x[lane < nb ? lane : 0];
     if (nb < 64) {
-        int d = 64 - nb; float v;
-        if (d < nb) { v = lane < 2 * d ? x[lane >> 1] : x[lane - d]; }
+        const int d = 64 - nb;
+        if (d < nb) c = lane < 2 * d ? x[lane >> 1] : x[lane - d];
         else {
-            float ratio = fabsf((float)(1.0 - 32.0 / (double)(float)nb));
-            int n4 = (int)round((double)(ratio * (float)nb));
-            int idx = lane < 4 * n4 ? (lane >> 2) : n4 + ((lane - 4 * n4) >> 1);
-            v = x[idx];
+            const float ratio = fabsf((float)(1.0 - 32.0 / (double)(float)nb));
+            const int n4 = (int)round((double)(ratio * (float)nb));
+            c = x[lane < 4 * n4 ? (lane >> 2) : n4 + ((lane - 4 * n4) >> 1)];
         }
-        LSYNC();
-        x[lane] = v;
-        LSYNC();
         nb = 64;
     }
-    {   /* smoothing + pre-emphasis */
-        float c = x[lane], m = lane > 0 ? x[lane - 1] : x[0], p = lane < 63 ? x[lane + 1] : x[63];
-        float s = (float)(0.5 * (double)c + 0.25 * (double)m + 0.25 * (double)p);
-        s = s * P->sns_preemph[lane];
-        LSYNC();
-        x[lane] = s;
-        LSYNC();
-    }
+    /* smoothing + pre-emphasis, neighbours through DPP-free shuffles */
+    const float c_up = __shfl_up(c, 1), c_dn = __shfl_down(c, 1);       /* shuffles stay outside the selects: every lane must execute them */
+    const float mm = lane > 0 ? c_up : c, pp = lane < 63 ? c_dn : c;
+    float s = (float)(0.5 * (double)c + 0.25 * (double)mm + 0.25 * (double)pp);
+    s = s * P->sns_preemph[lane];
     float sum = 0;
-    for (int i = 0; i < 64; i++) sum += x[i];
+    for (int i = 0; i < 64; i++) sum += rl_f(s, i);
     float mean = sum / (float)64;
     float nf = mean * P->c_1em4;
     nf = nf > P->c_2m32 ? nf : P->c_2m32;
-    float xv = x[lane];
-    if (xv < nf) xv = nf;
-    float xl = (float)((double)m_log2f(xv) / 2.0);
+    if (s < nf) s = nf;
+    const float xl = (float)((double)m_log2f(s) / 2.0);
+    float* tmp = &L.sm[SM_MISC];
+    LSYNC();
+    x[lane] = s;                                    /* the reference overwrites the energies in place */
     tmp[lane] = xl;
     LSYNC();
-    float* xl4 = &L.sm[SM_MISC + 64];
+    float v4 = 0;
     if (lane < 16) {
         const float W[6] = {(float)(1.0 / 12.0), (float)(2.0 / 12.0), (float)(3.0 / 12.0), (float)(3.0 / 12.0), (float)(2.0 / 12.0), (float)(1.0 / 12.0)};
         float t[6];
-        if (lane == 0) { t[0] = tmp[0]; for (int i = 0; i < 5; i++) t[1 + i] = tmp[i]; }
-        else if (lane == 15) { for (int i = 0; i < 5; i++) t[i] = tmp[59 + i]; t[5] = tmp[63]; }
-        else for (int i = 0; i < 6; i++) t[i] = tmp[lane * 4 - 1 + i];
-        float s = 0;
 #pragma unroll
-        for (int i = 0; i < 6; i++) s += t[i] * W[i];
-        xl4[lane] = s;
+        for (int i = 0; i < 6; i++) { int q = lane * 4 - 1 + i; q = q < 0 ? 0 : q > 63 ? 63 : q; t[i] = tmp[q]; }
+        float a = 0;
+#pragma unroll
+        for (int i = 0; i < 6; i++) a += t[i] * W[i];
+        v4 = a;
     }
-    LSYNC();
     sum = 0;
-    for (int i = 0; i < 16; i++) sum += xl4[i];
+    for (int i = 0; i < 16; i++) sum += rl_f(v4, i);
     mean = (float)((double)sum / ((double)(float)nb / 4.0));
-    float* g = &L.sm[SM_SCF];
-    if (lane < 16) g[lane] = P->sns_damping * (xl4[lane] - mean);
-    LSYNC();
+    float g = P->sns_damping * (v4 - mean);
     if (smooth) {
-        float gs = 0;
-        if (lane < 16) {
-            if (lane == 0) gs = (float)((double)(g[0] + g[1] + g[2]) / 3.0);
-            else if (lane == 1) gs = (float)((double)(g[0] + g[1] + g[2] + g[3]) / 4.0);
-            else if (lane == 14) gs = (float)((double)(g[12] + g[13] + g[14] + g[15]) / 4.0);
-            else if (lane == 15) gs = (float)((double)(g[13] + g[14] + g[15]) / 3.0);
-            else gs = (float)((double)(g[lane - 2] + g[lane - 1] + g[lane] + g[lane + 1] + g[lane + 2]) / 5.0);
-            xl4[lane] = gs;
-        }
-        LSYNC();
+        const float gm2 = __shfl_up(g, 2), gm1 = __shfl_up(g, 1), gp1 = __shfl_down(g, 1), gp2 = __shfl_down(g, 2);
+        float gs;
+        if (lane == 0) gs = (float)((double)(g + gp1 + gp2) / 3.0);
+        else if (lane == 1) gs = (float)((double)(gm1 + g + gp1 + gp2) / 4.0);
+        else if (lane == 14) gs = (float)((double)(gm2 + gm1 + g + gp1) / 4.0);
+        else if (lane == 15) gs = (float)((double)(gm2 + gm1 + g) / 3.0);
+        else gs = (float)((double)(gm2 + gm1 + g + gp1 + gp2) / 5.0);
         sum = 0;
-        for (int i = 0; i < 16; i++) sum += xl4[i];
+        for (int i = 0; i < 16; i++) sum += rl_f(gs, i);
         mean = sum / (float)16;
-        if (lane < 16) g[lane] = P->att_damping * (gs - mean);
-        LSYNC();
+        g = P->att_damping * (gs - mean);
     }
+    if (lane < 16) L.sm[SM_SCF + lane] = g;
+    LSYNC();
 }
 
-/* ---- PVQ pulse search R/sns_quantize_scf.c:43-136; one lane per search, scratch in LDS ---- */
-__device__ void pvq_search_lane(const lc3d_plan* __restrict__ P, const float* x_in, int dim, int pulses, float* xabs, int* y, float* ynorm)
+/* ---- PVQ pulse search R/sns_quantize_scf.c:43-136: one search per lane, everything in registers ---- */
+__device__ __forceinline__ void pvq_search_reg(const lc3d_plan* __restrict__ P, const float* x_in, int dim, int pulses, int* y_out, float* yn_out)
 {
+    float xabs[16]; int y[16];
     float xsum = 0, yy = 0, xy = 0;
-    for (int i = 0; i < dim; i++) xabs[i] = fabsf(x_in[i]);
-    for (int i = 0; i < dim; i++) xsum += xabs[i];
-    for (int i = 0; i < 17; i++) y[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { xabs[i] = i < dim ? fabsf(x_in[i]) : 0.0f; y[i] = 0; }
+#pragma unroll
+    for (int i = 0; i < 16; i++) if (i < dim) xsum += xabs[i];
     if (xsum > P->c_2m24) {
         int tot = 0;
-        float proj = (float)(pulses - 1) / xsum;
-        for (int i = 0; i < dim; i++) {
-            int yi = (int)floorf(xabs[i] * proj);
+        const float proj = (float)(pulses - 1) / xsum;
+#pragma unroll
+        for (int i = 0; i < 16; i++) if (i < dim) {
+            const int yi = (int)floorf(xabs[i] * proj);
             y[i] = yi; tot += yi;
             yy = yy + (float)(yi * yi);
             xy = xy + xabs[i] * (float)yi;
@@ -717,28 +794,39 @@ __device__ void pvq_search_lane(const lc3d_plan* __restrict__ P, const float* x_
         while (tot < pulses) {
             int imx = 0; float cnum = -P->c_2p15, cden = 0;
             yy = yy + 0.5f;
-            for (int i = 0; i < dim; i++) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) if (i < dim) {
                 float a = xy + xabs[i]; a = a * a;
-                float b = yy + (float)y[i];
+                const float b = yy + (float)y[i];
                 if (a * cden > b * cnum) { cnum = a; cden = b; imx = i; }
             }
-            xy = xy + xabs[imx]; yy = yy + (float)y[imx]; y[imx] = y[imx] + 1; tot++;
+            float xs = 0; int ys = 0;
+#pragma unroll
+            for (int i = 0; i < 16; i++) if (i == imx) { xs = xabs[i]; ys = y[i]; y[i] = ys + 1; }
+            xy = xy + xs; yy = yy + (float)ys; tot++;
         }
         yy = yy * 2.0f;
     } else {
-        if (dim > 1) { y[0] = pulses / 2; y[dim] = -(pulses - pulses / 2); yy = (float)(y[0] * y[0] + y[dim] * y[dim]); }
-        else { y[1] = pulses; yy = (float)(pulses * pulses); }
+        /* all-zero target: the reference puts the pulses at y[0] and (out of range) y[dim]; only y[0] is ever read back */
+        const int y0 = pulses / 2, yd = -(pulses - pulses / 2);
+        y[0] = y0;
+        yy = (float)(y0 * y0 + yd * yd);
     }
-    float g = (float)(1.0 / (double)sqrtf(yy));
-    for (int i = 0; i < dim; i++) { int s = x_in[i] >= 0 ? 1 : -1; int yi = y[i] * s; y[i] = yi; ynorm[i] = (float)yi * g; }
+    const float g = (float)(1.0 / (double)sqrtf(yy));
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        int yi = 0;
+        if (i < dim) { yi = x_in[i] >= 0 ? y[i] : -y[i]; }
+        y_out[i] = yi; yn_out[i] = i < dim ? (float)yi * g : 0.0f;
+    }
 }
 
-/* MPVQ enumeration R/sns_quantize_scf.c:138-163 (integer) */
+/* MPVQ enumeration R/sns_quantize_scf.c:138-163 (integer) over pulses held in LDS */
 __device__ void mpvq_index(const int* pulses, int len, int& ls, int& idx)
 {
     int k = 0; ls = -1; idx = 0;
     for (int pos = len - 1; pos >= 0; pos--) {
-        int pv = pulses[pos];
+        const int pv = pulses[pos];
         if (ls >= 0 && pv != 0) idx = 2 * idx + ls;
         if (pv > 0) ls = 0;
         if (pv < 0) ls = 1;
@@ -748,7 +836,7 @@ __device__ void mpvq_index(const int* pulses, int len, int& ls, int& idx)
 }
 
 /* ---- SNS vector quantiser R/sns_quantize_scf.c:165-430 (+ DCT-II(16) R/dct4.c:28-48, IDCT-II :19-41) ---- */
-__device__ void st_sns_vq(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
+STAGE void st_sns_vq(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
 {
     const float* env = &L.sm[SM_SCF];
     float* st1 = &L.sm[SM_ST1]; float* tgt = &L.sm[SM_TGT]; float* tgtp = &L.sm[SM_TGTP];
@@ -759,11 +847,11 @@ __device__ void st_sns_vq(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
         const float* cb = sec ? lc3t_sns_hf : lc3t_sns_lf;
         float sum = 0;
 #pragma unroll
-        for (int i = 0; i < 8; i++) { float d = env[8 * sec + i] - cb[c * 8 + i]; sum += d * d; }
+        for (int i = 0; i < 8; i++) { const float d = env[8 * sec + i] - cb[c * 8 + i]; sum += d * d; }
         int bi = c;
         wave_argmin_first(sum, bi, 32);
         if (c == 0) isc[I_SCF0 + sec] = bi;
-        if (c < 8) { float s = cb[bi * 8 + c]; st1[8 * sec + c] = s; tgtp[8 * sec + c] = env[8 * sec + c] - s; }
+        if (c < 8) { const float s = cb[bi * 8 + c]; st1[8 * sec + c] = s; tgtp[8 * sec + c] = env[8 * sec + c] - s; }
     }
     LSYNC();
     {   /* DCT-II(16): every lane runs the 16-point DFT on the same data, lanes < 16 keep one output */
@@ -781,20 +869,19 @@ __device__ void st_sns_vq(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
     /* four pulse searches, one lane each: 0:(N=10,K=10) 1:(N=6,K=1 on tgt+10) 2:(N=16,K=8) 3:(N=16,K=6) */
     float* pv = &L.sm[SM_PVQ];
     if (lane < 4) {
-        float* xabs = pv + lane * PVQ_STRIDE; int* y = (int*)(pv + lane * PVQ_STRIDE + 16); float* yn = pv + lane * PVQ_STRIDE + 33;
         const int dim = lane == 0 ? 10 : lane == 1 ? 6 : 16, K = lane == 0 ? 10 : lane == 1 ? 1 : lane == 2 ? 8 : 6;
-        for (int i = 0; i < 16; i++) yn[i] = 0;
-        pvq_search_lane(P, lane == 1 ? tgt + 10 : tgt, dim, K, xabs, y, yn);
+        pvq_search_reg(P, lane == 1 ? tgt + 10 : tgt, dim, K, (int*)(pv + lane * 32), pv + lane * 32 + 16);
     }
     LSYNC();
-    const int* pA = (const int*)(pv + 16); const int* pB = (const int*)(pv + PVQ_STRIDE + 16);
-    const int* pN = (const int*)(pv + 2 * PVQ_STRIDE + 16); const int* pF = (const int*)(pv + 3 * PVQ_STRIDE + 16);
-    const float* nA = pv + 33; const float* nN = pv + 2 * PVQ_STRIDE + 33; const float* nF = pv + 3 * PVQ_STRIDE + 33;
+    const int* pA = (const int*)(pv); const int* pB = (const int*)(pv + 32);
+    const int* pN = (const int*)(pv + 64); const int* pF = (const int*)(pv + 96);
+    const float* nA = pv + 16; const float* nN = pv + 64 + 16; const float* nF = pv + 96 + 16;
     /* yC = [pA(10) | pB(6)], normalised */
-    float sumy = 0;
-    for (int i = 0; i < 16; i++) { int yi = i < 10 ? pA[i] : pB[i - 10]; sumy += (float)(yi * yi); }
-    const float gf = (float)(1.0 / (double)sqrtf(sumy));
     const int yCl = lane < 16 ? (lane < 10 ? pA[lane] : pB[lane - 10]) : 0;
+    const float ysq = (float)(yCl * yCl);
+    float sumy = 0;
+    for (int i = 0; i < 16; i++) sumy += rl_f(ysq, i);
+    const float gf = (float)(1.0 / (double)sqrtf(sumy));
     const float yCn = (float)yCl * gf;
     const float nz = (lane < 10) ? nA[lane] : 0.0f;
     if (lane < 16) {
@@ -806,9 +893,9 @@ __device__ void st_sns_vq(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
     int idx = 0; float glob;
     {
         float err = INFINITY;
-        if (lane < 6) { float s = 0; for (int j = 0; j < 16; j++) { float d = tgt[j] - vec[lane * 16 + j]; s += d * d; } err = s; }
+        if (lane < 6) { float s = 0; for (int j = 0; j < 16; j++) { const float d = tgt[j] - vec[lane * 16 + j]; s += d * d; } err = s; }
         float min_err = P->c_2p15;
-        for (int i = 0; i < 6; i++) { float e = __shfl(err, i); if (e < min_err) { min_err = e; idx = i; } }
+        for (int i = 0; i < 6; i++) { const float e = rl_f(err, i); if (e < min_err) { min_err = e; idx = i; } }
         glob = lc3t_sns_gain_q[idx];
     }
     /* three inverse DCTs in parallel: lanes 0-15 split candidate, 16-31 near, 32-47 far */
@@ -820,6 +907,7 @@ __device__ void st_sns_vq(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
     if (lane < 48) {
         const float* in = &idc[lane & ~15]; const int i = lane & 15;
         float sum = 0;
+#pragma unroll
         for (int j = 0; j < 16; j++) {
             float t = (float)((double)in[j] * P->idct_cos[i * 16 + j]);
             if (j == 0) t *= P->c_idct_n2;
@@ -829,8 +917,17 @@ __device__ void st_sns_vq(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
     }
     LSYNC();
     const float* split = &idc[48]; const float* subN = &idc[64]; const float* subF = &idc[80];
-    float e_split = 0;
-    for (int i = 0; i < 16; i++) { float d = tgtp[i] - glob * split[i]; e_split += d * d; }
+    /* error of the split candidate and of the 4 near / 8 far gains: one serial 16-term sum per lane (0 split, 1-4 near, 5-12 far) */
+    float err = INFINITY;
+    if (lane < 13) {
+        const float g = lane == 0 ? glob : lane < 5 ? lc3t_sns_gain_near[lane - 1] : lc3t_sns_gain_far[lane - 5];
+        const float* sb = lane == 0 ? split : lane < 5 ? subN : subF;
+        float s = 0;
+        if (lane == 0) { for (int j = 0; j < 16; j++) { const float d = tgtp[j] - g * sb[j]; s += d * d; } }
+        else { for (int j = 0; j < 16; j++) s += (tgtp[j] - g * sb[j]) * (tgtp[j] - g * sb[j]); }
+        err = s;
+    }
+    const float e_split = rl_f(err, 0);
     int sub_mode = 0, sub_gain = 0, shape = 0;    /* shape: 0 = yC, 1 = pA only, 2 = near, 3 = far */
     float e_sofar = P->c_2p15, g_sel = 0; const float* v_sel = split;
     bool have = false;
@@ -838,31 +935,25 @@ __device__ void st_sns_vq(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
         if (idx <= 1) { sub_mode = 0; sub_gain = idx; shape = 0; } else { sub_mode = 1; sub_gain = idx - 2; shape = 1; }
         g_sel = glob; v_sel = split; e_sofar = e_split; have = true;
     }
-    {   /* near (4 gains, lanes 0-3) and far (8 gains, lanes 4-11) errors */
-        float err = INFINITY;
-        if (lane < 12) {
-            const float g = lane < 4 ? lc3t_sns_gain_near[lane] : lc3t_sns_gain_far[lane - 4];
-            const float* sb = lane < 4 ? subN : subF;
-            float s = 0;
-            for (int j = 0; j < 16; j++) { float d = tgtp[j] - g * sb[j]; s += d * d; }
-            err = s;
-        }
+    {
         float min_err = P->c_2p15; int gi = idx; float gg = glob;
-        for (int i = 0; i < 4; i++) { float e = __shfl(err, i); if (e < min_err) { gi = i; min_err = e; gg = lc3t_sns_gain_near[i]; } }
+        for (int i = 0; i < 4; i++) { const float e = rl_f(err, 1 + i); if (e < min_err) { gi = i; min_err = e; gg = lc3t_sns_gain_near[i]; } }
         if (min_err < e_sofar) { sub_mode = 2; sub_gain = gi; shape = 2; g_sel = gg; v_sel = subN; e_sofar = min_err; have = true; }
         min_err = P->c_2p15;
-        for (int i = 0; i < 8; i++) { float e = __shfl(err, 4 + i); if (e < min_err) { gi = i; min_err = e; gg = lc3t_sns_gain_far[i]; } }
+        for (int i = 0; i < 8; i++) { const float e = rl_f(err, 5 + i); if (e < min_err) { gi = i; min_err = e; gg = lc3t_sns_gain_far[i]; } }
         if (min_err < e_sofar) { sub_mode = 3; sub_gain = gi; shape = 3; g_sel = gg; v_sel = subF; have = true; }
     }
     if (lane < 16) {
-        float st2 = have ? g_sel * v_sel[lane] : 0.0f;
+        const float st2 = have ? g_sel * v_sel[lane] : 0.0f;
         L.sm[SM_SCFQ + lane] = st1[lane] + st2;
+        /* selected pulse vector for the MPVQ enumeration */
+        int pl = shape == 0 ? (lane < 10 ? pA[lane] : pB[lane - 10]) : shape == 1 ? (lane < 10 ? pA[lane] : 0) : shape == 2 ? pN[lane] : pF[lane];
+        if (!have) pl = 0;
+        ((int*)vec)[lane] = pl;
     }
+    LSYNC();
     if (lane == 0) {
-        int pulses[16];
-        for (int i = 0; i < 16; i++)
-            pulses[i] = shape == 0 ? (i < 10 ? pA[i] : pB[i - 10]) : shape == 1 ? (i < 10 ? pA[i] : 0) : shape == 2 ? pN[i] : pF[i];
-        if (!have) for (int i = 0; i < 16; i++) pulses[i] = 0;
+        const int* pulses = (const int*)vec;
         int ls, mi;
         if (sub_mode < 2) mpvq_index(pulses, 10, ls, mi); else mpvq_index(pulses, 16, ls, mi);
         int i6;
@@ -874,95 +965,253 @@ __device__ void st_sns_vq(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
 }
 
 /* ---- SNS interpolation R/sns_interpolate_scf.c:13-89 and spectral shaping R/mdct_shaping.c:13-22 ---- */
-__device__ void st_sns_apply(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
+STAGE void st_sns_apply(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
 {
     const float* g = &L.sm[SM_SCFQ];
     float* gi = &L.sm[SM_GI];
-    float* tmp = &L.sm[SM_MISC];
-    {
-        float v;
-        if (lane < 2) v = g[0];
-        else if (lane < 62) {
-            int n = (lane - 2) >> 2, r = (lane - 2) & 3;
-            float d = g[n + 1] - g[n];
-            double dd = (double)d;
-            if (r == 0) v = (float)((double)g[n] + dd / 8.0);
-            else if (r == 1) v = (float)((double)g[n] + 3.0 * dd / 8.0);
-            else if (r == 2) v = (float)((double)g[n] + 5.0 * dd / 8.0);
-            else v = (float)((double)g[n] + 7.0 * dd / 8.0);
-        } else {
-            double dd = (double)(g[15] - g[14]);
-            v = lane == 62 ? (float)((double)g[15] + dd / 8.0) : (float)((double)g[15] + 3.0 * dd / 8.0);
-        }
-        gi[lane] = v;
+    float v;
+    if (lane < 2) v = g[0];
+    else if (lane < 62) {
+        const int n = (lane - 2) >> 2, r = (lane - 2) & 3;
+        const double dd = (double)(g[n + 1] - g[n]);
+        if (r == 0) v = (float)((double)g[n] + dd / 8.0);
+        else if (r == 1) v = (float)((double)g[n] + 3.0 * dd / 8.0);
+        else if (r == 2) v = (float)((double)g[n] + 5.0 * dd / 8.0);
+        else v = (float)((double)g[n] + 7.0 * dd / 8.0);
+    } else {
+        const double dd = (double)(g[15] - g[14]);
+        v = lane == 62 ? (float)((double)g[15] + dd / 8.0) : (float)((double)g[15] + 3.0 * dd / 8.0);
     }
-    LSYNC();
     const int nb = P->nbands;
     if (nb < 64) {
+        gi[lane] = v;
+        LSYNC();
         const int d = 64 - nb;
-        float v = 0;
+        v = 0;
         if (d < 32) {
             if (lane < d) v = (float)((double)(gi[2 * lane] + gi[2 * lane + 1]) / 2.0);
             else if (lane < nb) v = gi[lane + d];
         } else {
-            float ratio = fabsf((float)(1.0 - 32.0 / (double)(float)nb));
-            int n4 = (int)round((double)(ratio * (float)nb));
+            const float ratio = fabsf((float)(1.0 - 32.0 / (double)(float)nb));
+            const int n4 = (int)round((double)(ratio * (float)nb));
             if (lane < n4) v = (float)((double)(gi[4 * lane] + gi[4 * lane + 1] + gi[4 * lane + 2] + gi[4 * lane + 3]) / 4.0);
-            else if (lane < nb) { int i = lane - n4; v = (float)((double)(gi[4 * n4 + 2 * i] + gi[4 * n4 + 2 * i + 1]) / 2.0); }
+            else if (lane < nb) { const int i = lane - n4; v = (float)((double)(gi[4 * n4 + 2 * i] + gi[4 * n4 + 2 * i + 1]) / 2.0); }
         }
         LSYNC();
-        gi[lane] = v;
-        LSYNC();
     }
-    if (lane < nb) { float v = -gi[lane]; tmp[lane] = m_powf(2.0f, v); }
-    LSYNC();
-    if (lane < nb) gi[lane] = tmp[lane];
+    if (lane < nb) gi[lane] = m_powf(2.0f, -v);
     LSYNC();
     for (int j = lane; j < P->N; j += WAVE) {
-        int b = P->band_of_bin[j];
-        if (b < nb) L.spec[j] = L.spec[j] * gi[b];
+        const int b = P->band_of_bin[j];
+        if (b < nb) L.A[j] = L.A[j] * gi[b];
     }
     LSYNC();
 }
 
-/* ---- TNS analysis + lattice filter R/tns_coder.c:170-362 ---- */
-__device__ void st_tns(const lc3d_plan* __restrict__ P, const lc3d_chan& C, WaveLds& L, int lane, int bw_idx, int bw_bin)
+/* ------------------------------------------------------------------------------------------------ */
+/* TNS: R/tns_coder.c:170-362                                                                        */
+/* ------------------------------------------------------------------------------------------------ */
+struct TnsGeom { int numfilters, maxOrder, nSub, start[2], stop[2]; float maxPG; int obits_off; };
+
+__device__ __forceinline__ TnsGeom tns_geom(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ C, int bw_idx, int bw_bin)
 {
-    int fs = P->fs, N = P->N; const int nBits = C.total_bits, dms = P->dms;
-    int numfilters = (fs >= 32000 && dms >= 50) ? 2 : 1;
-    int start[2] = {0, 0}, stop[2] = {0, 0};
+    TnsGeom g;
+    int fs = P->fs, N = P->N; const int nBits = C->total_bits, dms = P->dms;
+    g.numfilters = (fs >= 32000 && dms >= 50) ? 2 : 1;
+    g.start[0] = g.start[1] = g.stop[0] = g.stop[1] = 0;
     if ((double)N > 40 * ((double)(float)dms / 10.0)) { N = (int)(40 * ((double)(float)dms / 10.0)); fs = 40000; }
-    start[0] = (600 * N * 2 / fs) + 1;
-    if (numfilters == 1) stop[0] = N; else { start[1] = N / 2 + 1; stop[0] = N / 2; stop[1] = N; }
-    const int maxOrder = dms == 100 ? 8 : 4; const int nSub = dms == 100 ? 3 : 2;
-    float maxPG = 2; const float minPG = 1.5f;
-    const uint16_t* obits = &lc3t_tns_order_bits[8];
-    if ((dms >= 50 && (double)nBits >= 48 * ((double)(float)dms / 10.0)) || dms == 25) { maxPG = minPG; obits = &lc3t_tns_order_bits[0]; }
-    if (bw_idx >= 3 && numfilters == 2) { start[1] = bw_bin / 2 + 1; stop[0] = bw_bin / 2; stop[1] = bw_bin; }
-    else { numfilters = 1; stop[0] = bw_bin; }
-    float* racc = &L.sm[SM_MISC];              /* [f][sub][k] 2*3*9 = 54, then energies 6 at +54, r[f][9] at +64 */
-    int* isc = L.isc;
-    {   /* one serial sum per lane: lanes 0..53 autocorrelation terms, 54..59 sub-division energies */
+    g.start[0] = (600 * N * 2 / fs) + 1;
+    if (g.numfilters == 1) g.stop[0] = N; else { g.start[1] = N / 2 + 1; g.stop[0] = N / 2; g.stop[1] = N; }
+    g.maxOrder = dms == 100 ? 8 : 4; g.nSub = dms == 100 ? 3 : 2;
+    g.maxPG = 2; g.obits_off = 8;
+    if ((dms >= 50 && (double)nBits >= 48 * ((double)(float)dms / 10.0)) || dms == 25) { g.maxPG = 1.5f; g.obits_off = 0; }
+    if (bw_idx >= 3 && g.numfilters == 2) { g.start[1] = bw_bin / 2 + 1; g.stop[0] = bw_bin / 2; g.stop[1] = bw_bin; }
+    else { g.numfilters = 1; g.stop[0] = bw_bin; }
+    return g;
+}
+
+/* LPC weighting (total_bits < 480 only): polynomial weighting + step-down back to reflection coefficients,
+ * R/tns_coder.c:91-155,279-287.  Rare and index-heavy: lane 0 works in LDS scratch sc[]: a_in[9] at 36, rc_in[8] at 46. */
+STAGE void tns_lpc_weight(WaveLds& L, int lane, int maxOrder, float maxPG, float predGain)
+{
+    float* sc = &L.sm[SM_MISC + 112];
+    if (lane == 0) {
+        float* pa = sc + 56;                /* 9 */
+        pa[0] = 1;
+        for (int j = 1; j <= maxOrder - 1; j++) pa[j] = -sc[36 + maxOrder - j];
+        pa[maxOrder] = sc[46 + maxOrder - 1];
+        const float alpha = (float)((double)((maxPG - predGain)) * (0.85f - 1.0) / (double)(maxPG - 1.5f) + 1.0);
+        for (int i = 0; i <= maxOrder; i++) sc[i] = pa[i] * m_powf(alpha, (float)i);
+        int len = maxOrder + 1; const int len0 = len;
+        float* pa_ = sc; float* out = sc + 9; float* t0 = sc + 18; float* bf = sc + 26;
+        for (int i = 0; i < len - 1; i++) out[i] = 0;
+        { float a0 = pa_[0]; for (int i = 0; i < len; i++) { pa_[i] = pa_[i] / a0; a0 = pa_[0]; } }
+        out[len - 1] = pa_[len - 1];
+        for (int k = len0 - 2; k >= 0; k--) {
+            for (int i = 0; i < len - 1; i++) t0[i] = pa_[1 + i];
+            int l = len - 1;
+            const float knxt = t0[l - 1];
+            l = l - 1;
+            bf[0] = 1;
+            for (int i = 0; i < l; i++) {
+                const float t2 = knxt * t0[l - 1 - i];
+                bf[i + 1] = (float)((double)(t0[i] - t2) / (1.0 - (double)(fabsf(knxt) * fabsf(knxt))));
+            }
+            len = l + 1;
+            out[k] = bf[len - 1];
+            for (int i = 0; i < len; i++) pa_[i] = bf[i];
+        }
+        for (int i = 0; i < len0 - 1; i++) out[i] = out[i + 1];
+    }
+    LSYNC();
+}
+
+/* Levinson-Durbin (R/tns_coder.c:41-89), prediction gain, reflection-coefficient quantisation and bit count for filter f.
+ * Wave-uniform, fully unrolled for register residency.  Results: quantised rc -> sm[SM_MISC+104..], order / indices -> isc.
+ * Returns the number of bits this filter adds (flag included). */
+STAGE int tns_analyze(const lc3d_plan* __restrict__ P, WaveLds& L, int lane, int f, int maxOrder, float maxPG, int obits_off)
+{
+    const float* racc = &L.sm[SM_MISC];
+    float* rcs = &L.sm[SM_MISC + 104];
+    float r[9], a[9], rc[8], buf[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) { r[i] = unif(racc[64 + f * 9 + i]); a[i] = 0; }
+    float g = r[1] / r[0];
+    a[0] = g;
+    float v = (float)((1.0 - (double)(g * g)) * (double)r[0]);
+    rc[0] = -g;
+#pragma unroll
+    for (int t = 1; t < 8; t++) {
+        if (t < maxOrder) {
+            float sum = 0;
+#pragma unroll
+            for (int i = 1; i <= t; i++) sum += a[i - 1] * r[i];
+            g = (r[t + 1] - sum) / v;
+#pragma unroll
+            for (int j = 1; j <= t; j++) buf[j] = a[j - 1] - g * a[t - j];
+#pragma unroll
+            for (int j = 1; j <= t; j++) a[j] = buf[j];
+            a[0] = g;
+            v = v * (1 - g * g);
+            rc[t] = -g;
+        } else rc[t] = 0;
+    }
+    const float predGain = r[0] / v;
+    int tns = predGain > 1.5f;
+    int bits = 1, ord = 0; int idxq[8];
+    if (tns) {
+        if (predGain < maxPG) {
+            if (lane == 0) {
+                float* sc = &L.sm[SM_MISC + 112];
+#pragma unroll
+                for (int j = 0; j < 9; j++) sc[36 + j] = a[j];
+#pragma unroll
+                for (int j = 0; j < 8; j++) sc[46 + j] = rc[j];
+            }
+            LSYNC();
+            tns_lpc_weight(L, lane, maxOrder, maxPG, predGain);
+#pragma unroll
+            for (int i = 0; i < 8; i++) rc[i] = i < maxOrder ? unif(L.sm[SM_MISC + 112 + 9 + i]) : 0.0f;
+            LSYNC();
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            int ret = 0;
+            if (i < maxOrder) {
+#pragma unroll
+                for (int q = 0; q < 17; q++) if (rc[i] <= lc3t_tns_rc_thr[q + 1] && rc[i] > lc3t_tns_rc_thr[q]) ret = q;
+            }
+            idxq[i] = ret;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) { const float q = i < maxOrder ? lc3t_tns_rc_pts[idxq[i]] : 0.0f; rc[i] = q; if (i < maxOrder && q != 0) ord = i + 1; }
+        if (ord == 0) tns = 0;            /* would be undefined behaviour in the reference (R/tns_coder.c:311-321); filter off */
+    }
+    if (tns) {
+        int tmp = lc3t_tns_order_bits[obits_off + ord - 1];
+#pragma unroll
+        for (int i = 0; i < 8; i++) if (i < ord) tmp += lc3t_tns_coef_bits[i * 17 + idxq[i]];
+        bits += (tmp + 2047) >> 11;
+    }
+    if (lane == 0) {
+        L.isc[I_TNS_ORD0 + f] = tns ? ord : 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { if (tns && i < ord) L.isc[I_TNS_IDX0 + f * 8 + i] = idxq[i]; rcs[i] = rc[i]; }
+    }
+    LSYNC();
+    return bits;
+}
+
+/* Lattice MA filter of one TNS filter (R/tns_coder.c:339-357), lane-parallel with exact replay: each lane owns a run of
+ * consecutive bins and first replays the 8 preceding inputs; bins before the filter start come from the carried state. */
+STAGE void tns_lattice(WaveLds& L, int lane, int b_first, int cnt, int ord)
+{
+    float* stt = &L.sm[SM_MISC + 96];
+    const float* rcs = &L.sm[SM_MISC + 104];
+    float rc[8], st[8], carried[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) { rc[j] = unif(rcs[j]); carried[j] = unif(stt[j]); st[j] = carried[j]; }
+    const int chunk = (cnt + WAVE - 1) / WAVE;
+    const int b0 = b_first + lane * chunk;
+    int nmine = imin(chunk, b_first + cnt - b0); if (nmine < 0) nmine = 0;
+    for (int t = b0 - 8; nmine > 0 && t < b0 + nmine; t++) {
+        if (t < b_first) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) st[j] = carried[j];
+            continue;
+        }
+        float s = L.A[t], save = s;
+#pragma unroll
+        for (int j = 0; j < 7; j++) {
+            if (j < ord - 1) { const float tt = rc[j] * s + st[j]; s += rc[j] * st[j]; st[j] = save; save = tt; }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) if (j == ord - 1) { s += rc[j] * st[j]; st[j] = save; }
+        if (t >= b0) L.B[t] = s;
+    }
+    const int lastLane = (cnt - 1) / chunk;
+    LSYNC();
+    if (lane == lastLane) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) stt[j] = st[j];
+    }
+    for (int t = b_first + lane; t < b_first + cnt; t += WAVE) L.A[t] = L.B[t];
+    LSYNC();
+}
+
+STAGE void st_tns(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ C, WaveLds& L, int lane, int bw_idx, int bw_bin)
+{
+    const TnsGeom G = tns_geom(P, C, bw_idx, bw_bin);
+    float* racc = &L.sm[SM_MISC];              /* [f][sub][k] 2*3*9 = 54, sub-division energies 6 at +54, r[f][9] at +64 */
+    {   /* one serial sum per lane: lanes 0..53 autocorrelation terms, 54..59 sub-division energies (R/tns_coder.c:18-39,258-277) */
         int f, sub, k = -1;
-        if (lane < 54) { f = lane / 27; int r = lane % 27; sub = r / 9; k = r % 9; }
-        else { int r = lane - 54; f = r / 3; sub = r % 3; }
-        if (lane < 60 && f < numfilters && sub < nSub && (k <= maxOrder)) {
-            float sublen = (float)(((double)(float)stop[f] + 1.0 - (double)(float)start[f]) / (double)(float)nSub);
-            int lo = (int)(floor((double)(sublen * (float)sub)) + start[f] - 1);
-            int hi = (int)(floor((double)(sublen * (float)(sub + 1))) + start[f] - 1);
-            const float* x = &L.spec[lo]; const int n = hi - lo;
+        if (lane < 54) { f = lane / 27; const int r = lane % 27; sub = r / 9; k = r % 9; }
+        else { const int r = lane - 54; f = r / 3; sub = r % 3; }
+        if (lane < 60 && f < G.numfilters && sub < G.nSub && (k <= G.maxOrder)) {
+            const float sublen = (float)(((double)(float)G.stop[f] + 1.0 - (double)(float)G.start[f]) / (double)(float)G.nSub);
+            const int lo = (int)(floor((double)(sublen * (float)sub)) + G.start[f] - 1);
+            const int hi = (int)(floor((double)(sublen * (float)(sub + 1))) + G.start[f] - 1);
+            const float* x = &L.A[lo]; const int n = hi - lo;
             float acc = 0;
-            if (k < 0) { for (int i = 0; i < n; i++) acc += x[i] * x[i]; racc[54 + f * 3 + sub] = acc; }
-            else { for (int i = k; i < n; i++) acc += x[i] * x[i - k]; racc[lane] = acc; }
+            if (k < 0) {
+#pragma unroll 8
+                for (int i = 0; i < n; i++) acc += x[i] * x[i];
+                racc[54 + f * 3 + sub] = acc;
+            } else {
+                const float* xk = x - k;
+#pragma unroll 8
+                for (int i = k; i < n; i++) acc += x[i] * xk[i];
+                racc[lane] = acc;
+            }
         }
     }
     LSYNC();
-    if (lane < 18) {   /* r[f][k] */
-        int f = lane / 9, k = lane % 9;
+    if (lane < 18) {   /* r[f][k] with the reference's zero-energy escape, lag window */
+        const int f = lane / 9, k = lane % 9;
         float r = 0;
-        if (f < numfilters && k <= maxOrder) {
-            for (int sub = 0; sub < nSub; sub++) {
-                float e = racc[54 + f * 3 + sub];
+        if (f < G.numfilters && k <= G.maxOrder) {
+            for (int sub = 0; sub < G.nSub; sub++) {
+                const float e = racc[54 + f * 3 + sub];
                 if (e == 0) { r = (k == 0) ? 1.0f : 0.0f; break; }
                 r = r + racc[f * 27 + sub * 9 + k] / e;
             }
@@ -970,181 +1219,83 @@ __device__ void st_tns(const lc3d_plan* __restrict__ P, const lc3d_chan& C, Wave
         }
         racc[64 + lane] = r;
     }
+    if (lane >= 32 && lane < 40) L.sm[SM_MISC + 96 + lane - 32] = 0;     /* lattice state, persists from filter 0 to 1 */
     LSYNC();
     int bits = 0;
-    float* stt = &L.sm[SM_MISC + 96];          /* lattice state between filters: 8 */
-    float* rcs = &L.sm[SM_MISC + 104];         /* quantised rc of current filter: 8 */
-    if (lane < 8) stt[lane] = 0;
-    LSYNC();
-    for (int f = 0; f < numfilters; f++) {
-        /* Levinson-Durbin R/tns_coder.c:41-89, uniform across lanes, fully unrolled for register residency */
-        float r[9], a[9], rc[8], buf[9];
-#pragma unroll
-        for (int i = 0; i < 9; i++) { r[i] = racc[64 + f * 9 + i]; a[i] = 0; }
-        float g = r[1] / r[0];
-        a[0] = g;
-        float v = (float)((1.0 - (double)(g * g)) * (double)r[0]);
-        rc[0] = -g;
-#pragma unroll
-        for (int t = 1; t < 8; t++) {
-            if (t < maxOrder) {
-                float sum = 0;
-#pragma unroll
-                for (int i = 1; i <= t; i++) sum += a[i - 1] * r[i];
-                g = (r[t + 1] - sum) / v;
-#pragma unroll
-                for (int j = 1; j <= t; j++) buf[j] = a[j - 1] - g * a[t - j];
-#pragma unroll
-                for (int j = 1; j <= t; j++) a[j] = buf[j];
-                a[0] = g;
-                v = v * (1 - g * g);
-                rc[t] = -g;
-            } else rc[t] = 0;
-        }
-        const float err = v;
-        const float predGain = r[0] / err;
-        int tns = predGain > minPG;
-        bits++;
-        int ord = 0; int idxq[8];
-        if (tns) {
-            if (predGain < maxPG) {
-                /* LPC weighting (low rates): reorder to the polynomial, weight, back to reflection coeffs R/tns_coder.c:91-155,279-287.
-                 * Small, rare and index-heavy: lane 0 works in LDS scratch. */
-                float* sc = &L.sm[SM_MISC + 112];   /* a[9] at 0, out[9] at 9, t0[8] at 18, buf[9] at 26, a_in[9] at 36, rc_in[8] at 46 */
-                if (lane == 0) {
-#pragma unroll
-                    for (int j = 0; j < 9; j++) sc[36 + j] = a[j];
-#pragma unroll
-                    for (int j = 0; j < 8; j++) sc[46 + j] = rc[j];
-                    float* pa = sc + 56;                /* 9 */
-                    pa[0] = 1;
-                    for (int j = 1; j <= maxOrder - 1; j++) pa[j] = -sc[36 + maxOrder - j];
-                    pa[maxOrder] = sc[46 + maxOrder - 1];
-                    float alpha = (float)((double)((maxPG - predGain)) * (0.85f - 1.0) / (double)(maxPG - minPG) + 1.0);
-                    for (int i = 0; i <= maxOrder; i++) sc[i] = pa[i] * m_powf(alpha, (float)i);
-                    int len = maxOrder + 1; const int len0 = len;
-                    float* pa_ = sc; float* out = sc + 9; float* t0 = sc + 18; float* bf = sc + 26;
-                    for (int i = 0; i < len - 1; i++) out[i] = 0;
-                    { float a0 = pa_[0]; for (int i = 0; i < len; i++) { pa_[i] = pa_[i] / a0; a0 = pa_[0]; } }
-                    out[len - 1] = pa_[len - 1];
-                    for (int k = len0 - 2; k >= 0; k--) {
-                        for (int i = 0; i < len - 1; i++) t0[i] = pa_[1 + i];
-                        int l = len - 1;
-                        float knxt = t0[l - 1];
-                        l = l - 1;
-                        bf[0] = 1;
-                        for (int i = 0; i < l; i++) {
-                            float t2 = knxt * t0[l - 1 - i];
-                            bf[i + 1] = (float)((double)(t0[i] - t2) / (1.0 - (double)(fabsf(knxt) * fabsf(knxt))));
-                        }
-                        len = l + 1;
-                        out[k] = bf[len - 1];
-                        for (int i = 0; i < len; i++) pa_[i] = bf[i];
-                    }
-                    for (int i = 0; i < len0 - 1; i++) out[i] = out[i + 1];
-                }
-                LSYNC();
-#pragma unroll
-                for (int i = 0; i < 8; i++) rc[i] = i < maxOrder ? sc[9 + i] : 0.0f;
-                LSYNC();
-            }
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                int ret = 0;
-                if (i < maxOrder) for (int q = 0; q < 17; q++) if (rc[i] <= lc3t_tns_rc_thr[q + 1] && rc[i] > lc3t_tns_rc_thr[q]) ret = q;
-                idxq[i] = ret;
-            }
-#pragma unroll
-            for (int i = 0; i < 8; i++) { float q = i < maxOrder ? lc3t_tns_rc_pts[idxq[i]] : 0.0f; rc[i] = q; if (i < maxOrder && q != 0) ord = i + 1; }
-            if (ord == 0) tns = 0;
-        }
-        if (lane == 0) isc[I_TNS_ORD0 + f] = tns ? ord : 0;
-        if (tns) {
-            int tmp = obits[ord - 1];
-#pragma unroll
-            for (int i = 0; i < 8; i++) if (i < ord) tmp += lc3t_tns_coef_bits[i * 17 + idxq[i]];
-            bits = bits + ((tmp + 2047) >> 11);
-#pragma unroll
-            for (int i = 0; i < 8; i++) if (lane == 0 && i < ord) isc[I_TNS_IDX0 + f * 8 + i] = idxq[i];
-            /* lattice MA filter, lane-parallel with exact replay: each lane owns a run of consecutive bins and first
-             * replays the 8 preceding inputs (values before the filter start come from the carried state). */
-            const int b_first = start[f] - 1, cnt = stop[f] - start[f] + 1;
-            const int chunk = (cnt + WAVE - 1) / WAVE;
-            const int b0 = b_first + lane * chunk;
-            int nmine = imin(chunk, b_first + cnt - b0); if (nmine < 0) nmine = 0;
-            float st[8];
-#pragma unroll
-            for (int j = 0; j < 8; j++) st[j] = stt[j];
-            float carried[8];
-#pragma unroll
-            for (int j = 0; j < 8; j++) carried[j] = st[j];
-            for (int t = b0 - 8; nmine > 0 && t < b0 + nmine; t++) {
-                if (t < b_first) {
-#pragma unroll
-                    for (int j = 0; j < 8; j++) st[j] = carried[j];
-                    continue;
-                }
-                float s = L.spec[t], save = s;
-#pragma unroll
-                for (int j = 0; j < 7; j++) {
-                    if (j < ord - 1) { float tt = rc[j] * s + st[j]; s += rc[j] * st[j]; st[j] = save; save = tt; }
-                }
-#pragma unroll
-                for (int j = 0; j < 8; j++) if (j == ord - 1) { s += rc[j] * st[j]; st[j] = save; }
-                if (t >= b0) L.zb[t] = s;
-            }
-            const int lastLane = (cnt - 1) / chunk;
-            LSYNC();
-            if (lane == lastLane) {
-#pragma unroll
-                for (int j = 0; j < 8; j++) stt[j] = st[j];
-            }
-            for (int t = b_first + lane; t < b_first + cnt; t += WAVE) L.spec[t] = L.zb[t];
-            LSYNC();
-        }
+    for (int f = 0; f < G.numfilters; f++) {
+        bits += tns_analyze(P, L, lane, f, G.maxOrder, G.maxPG, G.obits_off);
+        const int ord = uni(L.isc[I_TNS_ORD0 + f]);
+        if (ord > 0) tns_lattice(L, lane, G.start[f] - 1, G.stop[f] - G.start[f] + 1, ord);
     }
-    if (lane == 0) { isc[I_TNS_NF] = numfilters; isc[I_TNS_BITS] = bits; }
+    if (lane == 0) { L.isc[I_TNS_NF] = G.numfilters; L.isc[I_TNS_BITS] = bits; }
     LSYNC();
-    (void)rcs;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* quantisation                                                                                      */
+/* ------------------------------------------------------------------------------------------------ */
+
+/* one bisection probe of R/estimate_global_gain.c:97-124 for this lane's candidate offset; the energies come from
+ * lane registers (e0: j < 64, e1: j >= 64) through readlane, so the 100-step serial chain never touches LDS */
+__device__ __forceinline__ bool gain_probe(const lc3d_plan* __restrict__ P, float e0, float e1, int nq, int cand, float target)
+{
+    float ener = 0; int iszero = 1;
+    const float fc = (float)cand, thr7 = P->c_thr7_up, thr50 = P->c_thr50_dn;
+#define GSTEP(ev) do { const float t = (ev) - fc; \
+        if (t < thr7) { if (iszero == 0) ener = (float)((double)ener + (2.7) * (28.0 / 20.0)); } \
+        else { if (t > thr50) ener = (float)((double)ener + 2.0 * (double)t - (50.0) * (28.0 / 20.0)); else ener = ener + t; iszero = 0; } } while (0)
+    for (int j = nq - 1; j >= 64; j--) GSTEP(rl_f(e1, j - 64));
+    for (int j = imin(nq, 64) - 1; j >= 0; j--) GSTEP(rl_f(e0, j));
+#undef GSTEP
+    return ener > target && iszero == 0;
 }
 
 /* ---- global gain estimate R/estimate_global_gain.c:30-137 ---- */
-__device__ void st_gain_estimate(const lc3d_plan* __restrict__ P, const lc3d_chan& C, WaveLds& L, Scal& S, int lane, int nbitsSQ,
-                                 float& gain, int& qgain, int& qmin)
+STAGE void st_gain_estimate(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ C, WaveLds& L, int lane, int nbitsSQ)
 {
-    const int lg = P->ylen, off = C.gg_off, nq = lg >> 2;
-    if (S.mem_target < 0) S.tbits_off = 0;
+    const int lg = P->ylen, off = C->gg_off, nq = lg >> 2;
+    float tbits_off = unif(L.fsc[F_TBITS_OFF]);
+    int mem_target = uni(L.isc[I_MEM_TARGET]); const int mem_spec = uni(L.isc[I_MEM_SPEC]);
+    if (mem_target < 0) tbits_off = 0;
     else {
-        float v = S.tbits_off + (float)S.mem_target - (float)S.mem_spec;
+        float v = tbits_off + (float)mem_target - (float)mem_spec;
         v = -40 > v ? -40 : v; v = 40 < v ? 40 : v;
-        S.tbits_off = (float)(0.8 * (double)S.tbits_off + 0.2 * (double)v);
+        tbits_off = (float)(0.8 * (double)tbits_off + 0.2 * (double)v);
     }
-    S.mem_target = nbitsSQ;
-    nbitsSQ = (int)((double)nbitsSQ + round((double)S.tbits_off));
+    mem_target = nbitsSQ;
+    nbitsSQ = (int)((double)nbitsSQ + round((double)tbits_off));
     float xm = 0;
-    for (int i = lane; i < lg; i += WAVE) xm = fmaxf(xm, fabsf(L.spec[i]));
-    const float x_max = wave_max_f(xm);
+    for (int i = lane; i < lg; i += WAVE) xm = fmaxf(xm, fabsf(L.A[i]));
+    const float x_max = unif(wave_max_f(xm));
     float reg_val = 0;
-    if (P->hrmode && C.reg_bits > 0) {
+    if (P->hrmode && C->reg_bits > 0) {
         float M0 = 1e-5f, M1 = 1e-5f; const float thresh = 2 * P->frame_ms;
-        for (int i = 0; i < lg; i++) { double ax = fabs((double)L.spec[i]); M0 = (float)((double)M0 + ax); M1 = (float)((double)M1 + (double)i * ax); }
-        float q = M1 / M0;
-        float rB = 8 * (1 - (q < thresh ? q : thresh) / thresh);
-        reg_val = x_max * m_powf(2.0f, (float)(-C.reg_bits) - rB);
+        for (int i0 = 0; i0 < lg; i0 += WAVE) {                      /* R/estimate_global_gain.c:58-62, serial in double */
+            const int i = i0 + lane;
+            const double ax = i < lg ? fabs((double)L.A[i]) : 0.0, ix = (double)i * ax;
+            const int cnt = imin(WAVE, lg - i0);
+            for (int k = 0; k < cnt; k++) { M0 = (float)((double)M0 + rl_d(ax, k)); M1 = (float)((double)M1 + rl_d(ix, k)); }
+        }
+        const float q = M1 / M0;
+        const float rB = 8 * (1 - (q < thresh ? q : thresh) / thresh);
+        reg_val = x_max * m_powf(2.0f, (float)(-C->reg_bits) - rB);
     }
     float ind = 0, ind_min = 0;
-    if (x_max == 0) { ind_min = (float)off; ind = 0; S.mem_target = -1; }
+    if (x_max == 0) { ind_min = (float)off; ind = 0; mem_target = -1; }
     else {
-        float g_min = P->hrmode == 1 ? x_max / (float)(32768 * 256 - 2) : (float)((double)x_max / (32768 - 0.375));
+        const float g_min = P->hrmode == 1 ? x_max / (float)(32768 * 256 - 2) : (float)((double)x_max / (32768 - 0.375));
         ind_min = (float)ceil(28.0 * (double)m_log10f(g_min));
-        float* en = L.za;
-        for (int j = lane; j < nq; j += WAVE) {
-            const float* x = &L.spec[4 * j];
-            float t = x[0] * x[0];
-            t += x[1] * x[1]; t += x[2] * x[2]; t += x[3] * x[3];
-            en[j] = (float)((28.0 / 20.0) * (7 + 10.0 * (double)m_log10f(t + reg_val + P->c_2m31)));
+        float e[2] = {0, 0};
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int j = lane + 64 * h;
+            if (j < nq) {
+                const float* x = &L.A[4 * j];
+                float t = x[0] * x[0];
+                t += x[1] * x[1]; t += x[2] * x[2]; t += x[3] * x[3];
+                e[h] = (float)((28.0 / 20.0) * (7 + 10.0 * (double)m_log10f(t + reg_val + P->c_2m31)));
+            }
         }
-        LSYNC();
         const float target = (float)((28.0 / 20.0) * (1.4) * (double)nbitsSQ);
         const int offset0 = 255 + off;
         /* 8-step bisection, evaluated speculatively: lanes 1..63 are the decision-tree nodes of the first six steps */
@@ -1152,70 +1303,54 @@ __device__ void st_gain_estimate(const lc3d_plan* __restrict__ P, const lc3d_cha
         {
             const int lvl = lane ? ilog2((unsigned)lane) : 0, p = lane - (1 << lvl);
             const int cand = offset0 - (p << (8 - lvl)) - (128 >> lvl);
-            float ener = 0; int iszero = 1;
-            for (int j = nq - 1; j >= 0; j--) {
-                float t = en[j] - (float)cand;
-                if ((double)t < (7.0) * (28.0 / 20.0)) { if (iszero == 0) ener = (float)((double)ener + (2.7) * (28.0 / 20.0)); }
-                else {
-                    if ((double)t > (50.0) * (28.0 / 20.0)) ener = (float)((double)ener + 2.0 * (double)t - (50.0) * (28.0 / 20.0));
-                    else ener = ener + t;
-                    iszero = 0;
-                }
-            }
-            const unsigned long long addback = __ballot(ener > target && iszero == 0);
+            const unsigned long long addback = __ballot(gain_probe(P, e[0], e[1], nq, cand, target));
             int node = 1;
-            for (int i = 0; i < 6; i++) { int nb = ((addback >> node) & 1ull) ? 0 : 1; m += nb << (7 - i); node = 2 * node + nb; }
+            for (int i = 0; i < 6; i++) { const int nb = ((addback >> node) & 1ull) ? 0 : 1; m += nb << (7 - i); node = 2 * node + nb; }
         }
         {   /* last two steps: lane 0: step 6; lane 1: step 7 if step 6 added back; lane 2: step 7 otherwise */
             const int cand = lane == 0 ? offset0 - m - 2 : lane == 1 ? offset0 - m - 1 : offset0 - m - 3;
-            float ener = 0; int iszero = 1;
-            for (int j = nq - 1; j >= 0; j--) {
-                float t = en[j] - (float)cand;
-                if ((double)t < (7.0) * (28.0 / 20.0)) { if (iszero == 0) ener = (float)((double)ener + (2.7) * (28.0 / 20.0)); }
-                else {
-                    if ((double)t > (50.0) * (28.0 / 20.0)) ener = (float)((double)ener + 2.0 * (double)t - (50.0) * (28.0 / 20.0));
-                    else ener = ener + t;
-                    iszero = 0;
-                }
-            }
-            const unsigned long long addback = __ballot(ener > target && iszero == 0);
+            const unsigned long long addback = __ballot(gain_probe(P, e[0], e[1], nq, cand, target));
             if (addback & 1ull) { if (!(addback & 2ull)) m += 1; }
             else { m += 2; if (!(addback & 4ull)) m += 1; }
         }
         const int offset = offset0 - m;
-        if ((float)offset < ind_min) S.mem_target = -1;
+        if ((float)offset < ind_min) mem_target = -1;
         ind = (ind_min > (float)offset ? ind_min : (float)offset) - (float)off;
-        LSYNC();
     }
-    qmin = (int)ind_min; qgain = (int)ind;
-    gain = P->gain_est[(int)(ind + (float)off) + 256];
+    if (lane == 0) {
+        L.fsc[F_TBITS_OFF] = tbits_off; L.isc[I_MEM_TARGET] = mem_target;
+        L.isc[I_GGMIN] = (int)ind_min; L.isc[I_GG] = (int)ind;
+        L.fsc[F_GAIN] = P->gain_est[(int)(ind + (float)off) + 256];
+    }
+    LSYNC();
 }
 
 /* ---- quantisation + exact bit estimate R/quantize_spec.c:26-197 ---- */
-__device__ void st_quantize(const lc3d_plan* __restrict__ P, const lc3d_chan& C, WaveLds& L, int lane, float gain, int mode, int target,
-                            int& nbits_o, int& nbits2_o, int& lastnz_o, int& lsb_o)
+STAGE void st_quantize(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ C, WaveLds& L, int lane, int mode, int target)
 {
-    const int nt = P->ylen, fs = P->fs, tb = C.total_bits;
+    const int nt = P->ylen, fs = P->fs, tb = C->total_bits;
     const float offs = P->hrmode ? 0.5f : 0.375f;
+    const float gain = unif(L.fsc[F_GAIN]);
+    int* xq = XQ(L); uint32_t* cd = CD(L); uint32_t* cf = CF(L);
     for (int i = lane; i < nt; i += WAVE) {
-        float x = L.spec[i];
-        int sg = x > 0 ? 1 : x < 0 ? -1 : 0;
-        L.xq[i] = (int)truncf(x / gain + offs * (float)sg);
+        const float x = L.A[i];
+        const int sg = x > 0 ? 1 : x < 0 ? -1 : 0;
+        xq[i] = (int)truncf(x / gain + offs * (float)sg);
     }
     int rate = 0;
     if ((fs < 48000 && tb > 320 + (fs / 8000 - 2) * 160) || (fs == 48000 && tb > 800)) rate = 512;
     if (mode == 0 && ((fs < 48000 && tb >= 640 + (fs / 8000 - 2) * 160) || (fs == 48000 && tb >= 1120))) mode = 1;
     LSYNC();
     int lp = 0;
-    for (int p = lane; p < (nt >> 1); p += WAVE) if (p >= 1 && (L.xq[2 * p] != 0 || L.xq[2 * p + 1] != 0)) lp = p;
-    lp = wave_max_i(lp);
+    for (int p = lane; p < (nt >> 1); p += WAVE) if (p >= 1 && (xq[2 * p] != 0 || xq[2 * p + 1] != 0)) lp = p;
+    lp = uni(wave_max_i(lp));
     const int lastnz = lp >= 1 ? 2 * lp + 1 : 1;
     const int ntup = (lastnz + 1) >> 1;
     int lastnz2 = mode < 0 ? lastnz + 1 : 2;
     int nbits2 = 0, base = 0, nlsb = 0, ct1 = 0, ct2 = 0;
     for (int c0 = 0; c0 < ntup; c0 += WAVE) {
         const int p = c0 + lane; const bool act = p < ntup;
-        const int x0 = act ? L.xq[2 * p] : 0, x1 = act ? L.xq[2 * p + 1] : 0;
+        const int x0 = act ? xq[2 * p] : 0, x1 = act ? xq[2 * p + 1] : 0;
         const int a0 = x0 < 0 ? -x0 : x0, b0 = x1 < 0 ? -x1 : x1, mx = imax(a0, b0);
         const int nsh = mx >= 4 ? ilog2((unsigned)mx) - 1 : 0;
         const int af = a0 >> nsh, bf = b0 >> nsh;
@@ -1230,7 +1365,7 @@ __device__ void st_quantize(const lc3d_plan* __restrict__ P, const lc3d_chan& C,
         if (act) {
             if (mode <= 0) bits += (imin(a0, 1) + imin(b0, 1)) * 2048;
             for (int lev = 0; lev < nsh; lev++) {
-                int pki = lc3t_ac_ctx_lut[tin + imin(lev, 3) * 1024];
+                const int pki = lc3t_ac_ctx_lut[tin + imin(lev, 3) * 1024];
                 bits += lc3t_ac_bits[pki * 17 + 16];
                 if (lev == 0 && mode > 0) lsbc += 2; else bits += 2 * 2048;
             }
@@ -1241,32 +1376,31 @@ __device__ void st_quantize(const lc3d_plan* __restrict__ P, const lc3d_chan& C,
                 if (lev1 > 0) { am >>= 1; bm >>= 1; if (am == 0 && x0 != 0) lsbc++; if (bm == 0 && x1 != 0) lsbc++; }
                 bits += (imin(am, 1) + imin(bm, 1)) * 2048;
             }
-            L.cd[p] = (uint32_t)tin | ((uint32_t)(maxlev + 1) << 10) | ((uint32_t)sym << 16);
+            cd[p] = (uint32_t)tin | ((uint32_t)(maxlev + 1) << 10) | ((uint32_t)sym << 16);
             const int pk2 = lc3t_ac_ctx_lut[tin + imin(imax(maxlev, 0), 3) * 1024];
             const uint32_t cl = lc3t_ac_cum[pk2 * 18 + sym], ch = lc3t_ac_cum[pk2 * 18 + sym + 1];
-            L.cf[p] = cl | ((ch - cl) << 16);
+            cf[p] = cl | ((ch - cl) << 16);
         }
         const int incl = wave_incl_scan_i(bits, lane) + base;
         const unsigned long long ok = __ballot(act && mode >= 0 && (a0 != 0 || b0 != 0) && incl <= target * 2048);
-        if (ok) { int hl = 63 - __clzll((long long)ok); lastnz2 = 2 * (c0 + hl) + 2; nbits2 = __shfl(incl, hl); }
-        base = __shfl(incl, 63);
-        nlsb += wave_sum_i(lsbc);
-        ct2 = __shfl(tval, 62); ct1 = __shfl(tval, 63);
+        if (ok) { const int hl = 63 - __clzll((long long)ok); lastnz2 = 2 * (c0 + hl) + 2; nbits2 = uni(__shfl(incl, hl)); }
+        base = uni(__shfl(incl, 63));
+        nlsb += uni(wave_sum_i(lsbc));
+        ct2 = uni(__shfl(tval, 62)); ct1 = uni(__shfl(tval, 63));
     }
     int nbits = (base + 2047) >> 11;
     if (mode >= 0) nbits2 = (nbits2 + 2047) >> 11; else nbits2 = nbits;
     if (mode > 0) { nbits += nlsb; nbits2 += nlsb; }
     LSYNC();
-    for (int i = lastnz2 + lane; i <= lastnz; i += WAVE) L.xq[i] = 0;
-    lsb_o = (mode > 0 && nbits > target) ? 1 : 0;
-    lastnz_o = lastnz2; nbits_o = nbits; nbits2_o = nbits2;
+    for (int i = lastnz2 + lane; i <= lastnz; i += WAVE) xq[i] = 0;
+    if (lane == 0) { L.isc[I_LSB] = (mode > 0 && nbits > target) ? 1 : 0; L.isc[I_LASTNZ] = lastnz2; L.isc[I_NBITS] = nbits; L.isc[I_NBITS2] = nbits2; }
     LSYNC();
 }
 
-/* ---- R/adjust_global_gain.c:13-50 ---- */
-__device__ void st_gain_adjust(const lc3d_plan* __restrict__ P, const lc3d_chan& C, int& gg, int gg_min, float& gain, int target, int nBits, int& change)
+/* ---- R/adjust_global_gain.c:13-50 (wave-uniform scalars) ---- */
+__device__ __forceinline__ void gain_adjust(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ C, int& gg, int gg_min, float& gain, int target, int nBits, int& change)
 {
-    const int f = P->fs_idx, off = C.gg_off;
+    const int f = P->fs_idx, off = C->gg_off;
     float delta;
     if (nBits < lc3t_gg_p1[f]) delta = (float)(((double)nBits + 48.0) / 16.0);
     else if (nBits < lc3t_gg_p2[f]) delta = ((float)nBits + lc3t_gg_d[f]) * lc3t_gg_c[f];
@@ -1287,10 +1421,12 @@ __device__ void st_gain_adjust(const lc3d_plan* __restrict__ P, const lc3d_chan&
 }
 
 /* ---- noise factor R/noise_factor.c:13-108 ---- */
-__device__ int st_noise_factor(const lc3d_plan* __restrict__ P, const lc3d_chan& C, WaveLds& L, int lane, float gg, int bw_bin)
+STAGE void st_noise_factor(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ C, WaveLds& L, int lane, int bw_bin)
 {
     const int width = P->dms == 100 ? 8 : 4, first = P->dms == 100 ? 24 : P->dms == 50 ? 12 : 6, hw = (width - 2) / 2;
-    float* val = L.za; int* zk = (int*)L.zb;
+    const float gg = unif(L.fsc[F_GAIN]);
+    const int* xq = XQ(L);
+    float* val = L.B; uint16_t* zk = ZKL(L);
     int nz = 0, sumz = 0;
     for (int k0 = first; k0 < bw_bin; k0 += WAVE) {
         const int k = k0 + lane;
@@ -1298,47 +1434,57 @@ __device__ int st_noise_factor(const lc3d_plan* __restrict__ P, const lc3d_chan&
         if (k < bw_bin) {
             allz = true;
             const int lo = k - hw, hi = imin(bw_bin - 1, k + hw);
-            for (int i = lo; i <= hi; i++) if (L.xq[i] != 0) allz = false;
+            for (int i = lo; i <= hi; i++) if (xq[i] != 0) allz = false;
         }
         const unsigned long long mk = __ballot(allz);
         if (allz) {
             const int pos = nz + __popcll(mk & ((1ull << lane) - 1ull));
-            val[pos] = fabsf(L.spec[k] / gg); zk[pos] = k + 1;
+            val[pos] = fabsf(L.A[k] / gg); zk[pos] = (uint16_t)(k + 1);
         }
         nz += __popcll(mk);
-        sumz += wave_sum_i(allz ? k + 1 : 0);
+        sumz += uni(wave_sum_i(allz ? k + 1 : 0));
     }
     LSYNC();
     float fac = 0;
-    if (sumz > 0) { float mean = 0; for (int j = 0; j < nz; j++) mean += val[j]; fac = mean / (float)nz; }
-    if (C.nbytes <= 20 && P->dms == 100 && nz > 0) {
-        const int m = sumz / nz; int j = 0, k = 0; float m1 = 0, m2 = 0;
-        for (int i = 0; i < nz; i++) { if (zk[i] <= m) { m1 += val[i]; j++; } else { m2 += val[i]; k++; } }
-        float n1 = m1 / (float)j, n2 = m2 / (float)k;
-        fac = n1 < n2 ? n1 : n2;
+    const bool split = C->nbytes <= 20 && P->dms == 100 && nz > 0;
+    const int msplit = split ? sumz / nz : 0x7fffffff;
+    float m1 = 0, m2 = 0; int j1 = 0;
+    for (int i0 = 0; i0 < nz; i0 += WAVE) {         /* serial float sums in index order, operands through readlane */
+        const int i = i0 + lane;
+        const float v = i < nz ? val[i] : 0.0f;
+        const bool lowgrp = i < nz && (int)zk[i] <= msplit;
+        const unsigned long long lm = __ballot(lowgrp);
+        const int cnt = imin(WAVE, nz - i0);
+        for (int k = 0; k < cnt; k++) { const float t = rl_f(v, k); if ((lm >> k) & 1ull) m1 += t; else m2 += t; }
+        j1 += __popcll(lm);
     }
+    if (sumz > 0) fac = m1 / (float)nz;              /* without the split every line is in the "low" group */
+    if (split) { const float n1 = m1 / (float)j1, n2 = m2 / (float)(nz - j1); fac = n1 < n2 ? n1 : n2; }
     float idx = (float)round((double)(8 - 16 * fac));
-    { float t = idx > 0 ? idx : 0; idx = t < 7 ? t : 7; }
+    { const float t = idx > 0 ? idx : 0; idx = t < 7 ? t : 7; }
+    if (lane == 0) L.isc[I_FACNS] = (int)idx;
     LSYNC();
-    return (int)idx;
 }
 
 /* ---- residual coding R/residual_coding.c:13-75 ---- */
-__device__ int st_residual(const lc3d_plan* __restrict__ P, WaveLds& L, int lane, float gain, int targetBits, int nBits)
+STAGE void st_residual(const lc3d_plan* __restrict__ P, WaveLds& L, int lane, int targetBits, int nBits)
 {
-    int* nzi = (int*)L.za;
+    uint16_t* nzi = (uint16_t*)L.B;
+    const int* xq = XQ(L);
+    const float gain = unif(L.fsc[F_GAIN]);
+    uint8_t* res = RESB(L);
     int nnz = 0;
     for (int k0 = 0; k0 < P->ylen; k0 += WAVE) {
         const int k = k0 + lane;
-        const bool nzq = k < P->ylen && L.xq[k] != 0;
+        const bool nzq = k < P->ylen && xq[k] != 0;
         const unsigned long long mk = __ballot(nzq);
-        if (nzq) nzi[nnz + __popcll(mk & ((1ull << lane) - 1ull))] = k;
+        if (nzq) nzi[nnz + __popcll(mk & ((1ull << lane) - 1ull))] = (uint16_t)k;
         nnz += __popcll(mk);
     }
     int m = targetBits - nBits + 4;
     if (P->hrmode) m += 10;
     const int iter_max = P->hrmode ? 20 : 1;
-    for (int i = lane; i < 160; i += WAVE) ((uint32_t*)L.res)[i] = 0;
+    for (int i = lane; i < 160; i += WAVE) ((uint32_t*)res)[i] = 0;
     LSYNC();
     int n = 0, iter = 0; float offset = .25f;
     while (iter < iter_max && n < m) {
@@ -1348,59 +1494,228 @@ __device__ int st_residual(const lc3d_plan* __restrict__ P, WaveLds& L, int lane
             int bit = 0;
             if (act) {
                 const int id = nzi[k];
-                const float x = L.spec[id];
-                if (x >= (float)L.xq[id] * gain) { bit = 1; L.spec[id] = x - gain * offset; } else { L.spec[id] = x + gain * offset; }
+                const float x = L.A[id];
+                if (x >= (float)xq[id] * gain) { bit = 1; L.A[id] = x - gain * offset; } else { L.A[id] = x + gain * offset; }
             }
             const unsigned long long bm = __ballot(bit);
-            const unsigned long long am = __ballot(act);
-            const int cnt = __popcll(am);
-            /* n is a multiple of 64 here except across iterations in hrmode; handle the general bit offset */
-            if (lane < 9) {
-                const int sh = n & 7; const int byte0 = n >> 3;
-                unsigned long long lo = bm << sh; unsigned hi = sh ? (unsigned)(bm >> (64 - sh)) : 0u;
-                unsigned v = lane < 8 ? (unsigned)((lo >> (8 * lane)) & 0xff) : (hi & 0xff);
-                if (byte0 + lane < 640 && v) L.res[byte0 + lane] |= (uint8_t)v;
+            const int cnt = __popcll(__ballot(act));
+            if (lane < 3) {                          /* 64 fresh bits at bit offset n: three word-granular ORs */
+                const int sh = n & 31, w0 = n >> 5;
+                const unsigned lo = (unsigned)bm, hi = (unsigned)(bm >> 32);
+                const unsigned v = lane == 0 ? lo << sh : lane == 1 ? ((sh ? lo >> (32 - sh) : 0u) | (hi << sh)) : (sh ? hi >> (32 - sh) : 0u);
+                if (v && w0 + lane < 160) atomicOr(&((unsigned*)res)[w0 + lane], v);
             }
             n += cnt;
             LSYNC();
         }
         iter++; offset *= .5f;
     }
-    return n;
+    if (lane == 0) L.isc[I_NRES] = n;
+    LSYNC();
 }
 
-/* ---- bitstream writers: side information R/enc_entropy.c:13-115, range coder R/ari_codec.c:511-800.
- * Integer code; runs on lane 0 with the frame bytes in LDS. ---- */
-struct BitW { uint8_t* p; int bp_side, mask_side; int bp, low, range, cache, carry, carry_count; };
+/* ---- bitstream: side information R/enc_entropy.c:13-115, range coder R/ari_codec.c:511-800 (integer, bit-exact).
+ *
+ * The frame has two cursors: the range coder writes bytes FORWARD from byte 0, everything else (side info, escape LSBs,
+ * signs, residual) is written BACKWARD bit by bit from the last byte.  The backward stream does not depend on the coder
+ * state, so it is assembled in parallel: every lane builds the bit string of its 2-tuple, a wave scan gives the bit
+ * offsets and the strings are OR-ed into LDS.  Only the range coder itself is serial; it runs on wave-uniform values
+ * (readlane -> scalar registers), its output bytes are collected with writelane and stored 64 at a time. ---- */
 
-__device__ __forceinline__ void put_bit_back(BitW& w, int bit)
+/* OR the n (<= 56) low bits of v into the backward stream at bit position q (bit 0 = LSB of the last frame byte) */
+__device__ __forceinline__ void or_bits_back(uint8_t* bytes, int nbytes, int q, unsigned long long v, int n)
 {
-    uint8_t v = w.p[w.bp_side];
-    v = bit ? (uint8_t)(v | w.mask_side) : (uint8_t)(v & (255 - w.mask_side));
-    w.p[w.bp_side] = v;
-    if (w.mask_side == 128) { w.mask_side = 1; w.bp_side--; } else w.mask_side *= 2;
+    if (n <= 0) return;
+    v &= (n >= 64) ? ~0ull : ((1ull << n) - 1ull);
+    const unsigned long long V = v << (q & 7);
+    const int A0 = nbytes - 1 - (q >> 3), w0 = A0 >> 2;
+    unsigned m0 = 0, m1 = 0, m2 = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        const unsigned b = (unsigned)((V >> (8 * i)) & 0xffull);
+        const int A = A0 - i, d = w0 - (A >> 2);
+        const unsigned val = b << (8 * (A & 3));
+        if (d == 0) m0 |= val; else if (d == 1) m1 |= val; else m2 |= val;
+    }
+    unsigned* W = (unsigned*)bytes;
+    if (m0) atomicOr(&W[w0], m0);
+    if (m1) atomicOr(&W[w0 - 1], m1);
+    if (m2) atomicOr(&W[w0 - 2], m2);
 }
-__device__ __forceinline__ void put_uint_back(BitW& w, int val, int nbits) { for (int k = 0; k < nbits; k++) { put_bit_back(w, val & 1); val = val / 2; } }
-__device__ __forceinline__ void ac_shift(BitW& w)
+/* OR n (<= 32) bits into a forward little-endian bit buffer (LSB mode list) */
+__device__ __forceinline__ void or_bits_fwd(uint8_t* buf, int q, unsigned v, int n)
+{
+    if (n <= 0) return;
+    const unsigned long long V = (unsigned long long)v << (q & 31);
+    unsigned* W = (unsigned*)buf;
+    if ((unsigned)V) atomicOr(&W[q >> 5], (unsigned)V);
+    if ((unsigned)(V >> 32)) atomicOr(&W[(q >> 5) + 1], (unsigned)(V >> 32));
+}
+
+struct AriSt { int bp, low, range, cache, carry, carry_count; int fw; };
+
+__device__ __forceinline__ void ari_emit(AriSt& w, uint8_t* bytes, int lane, int b)
+{
+    w.fw = (lane == (w.bp & 63)) ? b : w.fw;
+    w.bp++;
+    if ((w.bp & 63) == 0) bytes[w.bp - 64 + lane] = (uint8_t)w.fw;
+}
+__device__ __forceinline__ void ari_flush(AriSt& w, uint8_t* bytes, int lane)
+{
+    if (lane < (w.bp & 63)) bytes[(w.bp & ~63) + lane] = (uint8_t)w.fw;
+}
+__device__ __forceinline__ void ari_shift(AriSt& w, uint8_t* bytes, int lane)     /* R/ari_codec.c:531-553 */
 {
     if (w.low < 16711680 || w.carry == 1) {
-        if (w.cache >= 0) { w.p[w.bp] = (uint8_t)(w.cache + w.carry); w.bp++; }
-        while (w.carry_count > 0) { w.p[w.bp] = (uint8_t)((w.carry + 255) & 255); w.bp++; w.carry_count--; }
+        if (w.cache >= 0) ari_emit(w, bytes, lane, w.cache + w.carry);
+        while (w.carry_count > 0) { ari_emit(w, bytes, lane, (w.carry + 255) & 255); w.carry_count--; }
         w.cache = w.low >> 16; w.carry = 0;
     } else w.carry_count++;
     w.low = (w.low << 8) & 0xFFFFFF;
 }
-__device__ __forceinline__ void ac_encode(BitW& w, int freq, int cum)
+__device__ __forceinline__ void ari_encode(AriSt& w, uint8_t* bytes, int lane, int freq, int cum)   /* R/ari_codec.c:511-529 */
 {
-    int r = w.range >> 10;
+    const int r = w.range >> 10;
     w.low += r * cum;
     if ((w.low >> 24) == 1) w.carry = 1;
     w.low &= 0xFFFFFF;
     w.range = r * freq;
-    while (w.range < 65536) { w.range <<= 8; ac_shift(w); }
+    while (w.range < 65536) { w.range <<= 8; ari_shift(w, bytes, lane); }
 }
-__device__ void ac_finish(BitW& w)
+
+STAGE void st_bitstream(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ C, WaveLds& L, int lane)
 {
+    int* isc = L.isc;
+    uint8_t* bytes = L.bytes;
+    const int nbytes = C->nbytes;
+    const int nfilt = uni(isc[I_TNS_NF]);
+    const int lastnz = uni(isc[I_LASTNZ]), lsbMode = uni(isc[I_LSB]), nres = uni(isc[I_NRES]);
+    const int bw_idx = uni(isc[I_BW]), gg = uni(isc[I_GG]), fac_ns = uni(isc[I_FACNS]);
+    const int* xq = XQ(L); const uint32_t* cd = CD(L); const uint32_t* cf = CF(L); uint8_t* resb = RESB(L);
+    /* ---- side information: fields appended LSB-first into a 128-bit accumulator (uniform), R/enc_entropy.c:25-87 ---- */
+    unsigned long long slo = 0, shi = 0; int Q = 0;
+#define SIDE(val_, n_) do { unsigned long long v_ = (unsigned long long)(unsigned)(val_) & (((n_) >= 32) ? 0xffffffffull : ((1ull << (n_)) - 1ull)); \
+        if (Q < 64) { slo |= v_ << Q; if (Q + (n_) > 64) shi |= v_ >> (64 - Q); } else shi |= v_ << (Q - 64); Q += (n_); } while (0)
+    {
+        const int gain_msb_bits[4] = {1, 1, 2, 2}, gain_lsb_bits[4] = {0, 1, 0, 1};
+        if (P->bw_bits > 0) SIDE(bw_idx, P->bw_bits);
+        SIDE(lastnz / 2 - 1, ilog2((unsigned)(P->ylen / 2 - 1)) + 1);
+        SIDE(lsbMode, 1);
+        SIDE(gg, 8);
+        for (int i = 0; i < nfilt; i++) SIDE(imin(1, isc[I_TNS_ORD0 + i]), 1);
+        SIDE(isc[I_LTPF0], 1);
+        SIDE(isc[I_SCF0], 5); SIDE(isc[I_SCF1], 5);
+        const int s2 = isc[I_SCF2], s3 = isc[I_SCF3];
+        const int sub_msb = s2 / 2, sub_lsb = s2 & 1;
+        SIDE(sub_msb, 1);
+        const int g_msb = s3 >> gain_lsb_bits[s2], g_lsb = s3 & 1;
+        SIDE(g_msb, gain_msb_bits[s2]);
+        SIDE(isc[I_SCF4], 1);
+        if (sub_msb == 0) {
+            int t = sub_lsb == 0 ? isc[I_SCF6] + 2 : g_lsb;
+            t = t * 2390004 + isc[I_SCF5];
+            SIDE(t, 25);
+        } else {
+            int t = isc[I_SCF5];
+            if (sub_lsb != 0) t = 2 * t + g_lsb + 15158272;
+            SIDE(t, 24);
+        }
+        if (isc[I_LTPF0] == 1) { SIDE(isc[I_LTPF1], 1); SIDE(isc[I_LTPF2], 9); }
+        SIDE(fac_ns, 3);
+    }
+#undef SIDE
+    Q = uni(Q);
+    if (lane < 4) {
+        const unsigned piece = lane == 0 ? (unsigned)slo : lane == 1 ? (unsigned)(slo >> 32) : lane == 2 ? (unsigned)shi : (unsigned)(shi >> 32);
+        or_bits_back(bytes, nbytes, 32 * lane, piece, imin(32, Q - 32 * lane));
+    }
+    if (lane == 0) { isc[I_BP_SIDE] = nbytes - 1 - (Q >> 3); isc[I_MASK_SIDE] = 1 << (Q & 7); }
+
+    /* ---- range coder: TNS symbols ---- */
+    AriSt w; w.bp = 0; w.low = 0; w.range = 0xFFFFFF; w.cache = -1; w.carry = 0; w.carry_count = 0; w.fw = 0;
+    for (int i = 0; i < nfilt; i++) {
+        const int ord = uni(isc[I_TNS_ORD0 + i]);
+        if (ord > 0) {
+            const uint16_t* oc = &lc3t_tns_order_cum[C->lpc_weighting * 9];
+            ari_encode(w, bytes, lane, uni(oc[ord] - oc[ord - 1]), uni(oc[ord - 1]));
+            for (int j = 0; j < ord; j++) {
+                const uint16_t* cc = &lc3t_tns_coef_cum[j * 18]; const int id = uni(isc[I_TNS_IDX0 + i * 8 + j]);
+                ari_encode(w, bytes, lane, uni(cc[id + 1] - cc[id]), uni(cc[id]));
+            }
+        }
+    }
+    /* ---- spectrum: 64 tuples per pass ---- */
+    const int ntup = (lastnz + 1) >> 1;
+    int nl = 0;                                   /* LSB-mode list length */
+    for (int c0 = 0; c0 < ntup; c0 += WAVE) {
+        const int p = c0 + lane; const bool act = p < ntup;
+        const uint32_t cdv = act ? cd[p] : 0u, cfv = act ? cf[p] : 0u;
+        const int x0 = act ? xq[2 * p] : 0, x1 = act ? xq[2 * p + 1] : 0;
+        const int a0 = x0 < 0 ? -x0 : x0, b0 = x1 < 0 ? -x1 : x1;
+        const int ctx = cdv & 1023, maxlev = act ? (int)((cdv >> 10) & 63) - 1 : -1;
+        /* escape symbol models for level classes 0..3 */
+        unsigned e0 = 0, e1 = 0, e2 = 0, e3 = 0;
+        if (maxlev > 0) {
+            { const uint16_t* q = &lc3t_ac_cum[lc3t_ac_ctx_lut[ctx] * 18]; e0 = q[16] | ((unsigned)(q[17] - q[16]) << 16); }
+            if (maxlev > 1) { const uint16_t* q = &lc3t_ac_cum[lc3t_ac_ctx_lut[ctx + 1024] * 18]; e1 = q[16] | ((unsigned)(q[17] - q[16]) << 16); }
+            if (maxlev > 2) { const uint16_t* q = &lc3t_ac_cum[lc3t_ac_ctx_lut[ctx + 2048] * 18]; e2 = q[16] | ((unsigned)(q[17] - q[16]) << 16); }
+            if (maxlev > 3) { const uint16_t* q = &lc3t_ac_cum[lc3t_ac_ctx_lut[ctx + 3072] * 18]; e3 = q[16] | ((unsigned)(q[17] - q[16]) << 16); }
+        }
+        /* backward bits of this tuple: escape LSB pairs, then signs (R/ari_codec.c:700-757) */
+        unsigned long long bits = 0; int n = 0;
+        for (int lev = 0; lev < maxlev; lev++) {
+            if (!(lsbMode == 1 && lev == 0)) {
+                bits |= (unsigned long long)((a0 >> lev) & 1) << n; n++;
+                bits |= (unsigned long long)((b0 >> lev) & 1) << n; n++;
+            }
+        }
+        int a = a0, b = b0; unsigned lsbv = 0; int ln = 0;
+        if (lsbMode == 1 && maxlev > 0) {
+            a >>= 1; lsbv |= (unsigned)(a0 & 1) << ln; ln++;
+            if (a == 0 && x0 != 0) { lsbv |= (unsigned)(x0 < 0) << ln; ln++; }
+            b >>= 1; lsbv |= (unsigned)(b0 & 1) << ln; ln++;
+            if (b == 0 && x1 != 0) { lsbv |= (unsigned)(x1 < 0) << ln; ln++; }
+        }
+        if (a != 0) { bits |= (unsigned long long)(x0 < 0) << n; n++; }
+        if (b != 0) { bits |= (unsigned long long)(x1 < 0) << n; n++; }
+        const int incl = wave_incl_scan_i(n, lane);
+        or_bits_back(bytes, nbytes, Q + incl - n, bits, n);
+        Q += uni(__shfl(incl, 63));
+        if (lsbMode == 1) {
+            const int li = wave_incl_scan_i(ln, lane);
+            or_bits_fwd(resb, nl + li - ln, lsbv, ln);
+            nl += uni(__shfl(li, 63));
+        }
+        /* serial part: wave-uniform */
+        const int cnt = imin(WAVE, ntup - c0);
+        for (int j = 0; j < cnt; j++) {
+            const int ml = __builtin_amdgcn_readlane(maxlev, j);
+            if (ml > 0) {
+                for (int lev = 0; lev < ml; lev++) {
+                    const unsigned ev = lev == 0 ? (unsigned)__builtin_amdgcn_readlane((int)e0, j) : lev == 1 ? (unsigned)__builtin_amdgcn_readlane((int)e1, j)
+                                      : lev == 2 ? (unsigned)__builtin_amdgcn_readlane((int)e2, j) : (unsigned)__builtin_amdgcn_readlane((int)e3, j);
+                    ari_encode(w, bytes, lane, (int)(ev >> 16), (int)(ev & 0xffff));
+                }
+            }
+            const unsigned fv = (unsigned)__builtin_amdgcn_readlane((int)cfv, j);
+            ari_encode(w, bytes, lane, (int)(fv >> 16), (int)(fv & 0xffff));
+        }
+    }
+    /* ---- residual / LSB bits (R/ari_codec.c:764-797) ---- */
+    const int total = C->total_bits;
+    const int bp_side = nbytes - 1 - (Q >> 3), mask_log = Q & 7;
+    const int nbits_side = total - (8 * (bp_side + 1) + 8 - mask_log);
+    int nbits_ari = (w.bp + 1) * 8 + 25 - flog2f_int((unsigned)w.range);
+    if (w.cache >= 0) nbits_ari += 8;
+    if (w.carry_count > 0) nbits_ari += w.carry_count * 8;
+    int nres_enc = total - (nbits_side + nbits_ari);
+    nres_enc = imin(nres_enc, lsbMode == 0 ? nres : nl);
+    LSYNC();                                        /* LSB list / residual bits are complete */
+    for (int k0 = 32 * lane; k0 < nres_enc; k0 += 32 * WAVE) {
+        const unsigned wv = ((const unsigned*)resb)[k0 >> 5];
+        or_bits_back(bytes, nbytes, Q + k0, wv, imin(32, nres_enc - k0));
+    }
+    /* ---- finalise the range coder (R/ari_codec.c:573-647) ---- */
     int bits = 24 - flog2f_int((unsigned)w.range);
     int mask = 0xFFFFFF >> bits, val = w.low + mask, over1 = val >> 24;
     val &= 0xFFFFFF;
@@ -1413,106 +1728,23 @@ __device__ void ac_finish(BitW& w)
     }
     w.low = val;
     int b = bits;
-    if (bits > 8) { for (; b >= 1; b -= 8) ac_shift(w); } else ac_shift(w);
+    if (bits > 8) { for (; b >= 1; b -= 8) ari_shift(w, bytes, lane); } else ari_shift(w, bytes, lane);
     bits = b; if (bits < 0) bits += 8;
     int last; const int nb = bits;
     if (w.carry_count > 0) {
-        w.p[w.bp++] = (uint8_t)w.cache;
-        for (int c = w.carry_count; c >= 2; c--) w.p[w.bp++] = 255;
+        ari_emit(w, bytes, lane, w.cache);
+        for (int c = w.carry_count; c >= 2; c--) ari_emit(w, bytes, lane, 255);
         last = 255 << (bits - 8);
     } else last = w.cache;
-    uint8_t v = w.p[w.bp];
-    for (int k = 0, m = 128; k < nb; k++, m >>= 1) { if ((last & m) == 0) v &= (uint8_t)(255 - m); else v |= (uint8_t)m; }
-    w.p[w.bp] = v;
+    ari_flush(w, bytes, lane);
+    LSYNC();                                        /* all forward bytes and backward ORs have landed */
+    if (lane == 0) {
+        uint8_t v = bytes[w.bp];
+        for (int k = 0, m = 128; k < nb; k++, m >>= 1) { if ((last & m) == 0) v &= (uint8_t)(255 - m); else v |= (uint8_t)m; }
+        bytes[w.bp] = v;
+    }
 }
 
-__device__ void st_bitstream(const lc3d_plan* __restrict__ P, const lc3d_chan& C, WaveLds& L, int bw_idx, int lastnz, int lsbMode, int gg,
-                             int fac_ns, int nres, int* dbg_bp_side, int* dbg_mask_side)
-{
-    const int* isc = L.isc;
-    BitW w; w.p = L.bytes;
-    w.bp_side = C.nbytes - 1; w.mask_side = 1;
-    const int nfilt = isc[I_TNS_NF];
-    {   /* side information */
-        const int gain_msb_bits[4] = {1, 1, 2, 2}, gain_lsb_bits[4] = {0, 1, 0, 1};
-        if (P->bw_bits > 0) put_uint_back(w, bw_idx, P->bw_bits);
-        put_uint_back(w, lastnz / 2 - 1, ilog2((unsigned)(P->ylen / 2 - 1)) + 1);       /* ceil(log2(ylen/2)) */
-        put_bit_back(w, lsbMode);
-        put_uint_back(w, gg, 8);
-        for (int i = 0; i < nfilt; i++) put_bit_back(w, imin(1, isc[I_TNS_ORD0 + i]));
-        put_bit_back(w, isc[I_LTPF0]);
-        put_uint_back(w, isc[I_SCF0], 5); put_uint_back(w, isc[I_SCF1], 5);
-        const int s2 = isc[I_SCF2], s3 = isc[I_SCF3];
-        const int sub_msb = s2 / 2, sub_lsb = s2 & 1;
-        put_bit_back(w, sub_msb);
-        const int g_msb = s3 >> gain_lsb_bits[s2], g_lsb = s3 & 1;
-        put_uint_back(w, g_msb, gain_msb_bits[s2]);
-        put_bit_back(w, isc[I_SCF4]);
-        if (sub_msb == 0) {
-            int t = sub_lsb == 0 ? isc[I_SCF6] + 2 : g_lsb;
-            t = t * 2390004 + isc[I_SCF5];
-            put_uint_back(w, t, 25);
-        } else {
-            int t = isc[I_SCF5];
-            if (sub_lsb != 0) t = 2 * t + g_lsb + 15158272;
-            put_uint_back(w, t, 24);
-        }
-        if (isc[I_LTPF0] == 1) { put_uint_back(w, isc[I_LTPF1], 1); put_uint_back(w, isc[I_LTPF2], 9); }
-        put_uint_back(w, fac_ns, 3);
-    }
-    if (dbg_bp_side) { *dbg_bp_side = w.bp_side; *dbg_mask_side = w.mask_side; }
-    /* range coder */
-    w.bp = 0; w.low = 0; w.range = 0xFFFFFF; w.cache = -1; w.carry = 0; w.carry_count = 0;
-    for (int i = 0; i < nfilt; i++) {
-        const int ord = isc[I_TNS_ORD0 + i];
-        if (ord > 0) {
-            const uint16_t* oc = &lc3t_tns_order_cum[C.lpc_weighting * 9];
-            ac_encode(w, oc[ord] - oc[ord - 1], oc[ord - 1]);
-            for (int j = 0; j < ord; j++) {
-                const uint16_t* cc = &lc3t_tns_coef_cum[j * 18]; const int id = isc[I_TNS_IDX0 + i * 8 + j];
-                ac_encode(w, cc[id + 1] - cc[id], cc[id]);
-            }
-        }
-    }
-    uint8_t* lsbs = L.res + 0;   /* lsbMode==1: residual bits are not produced, reuse the buffer bit-packed from byte 0 */
-    int nl = 0, lsb1 = 0, lsb2 = 0;
-    for (int k = 0; k < lastnz; k += 2) {
-        const uint32_t cdv = L.cd[k >> 1];
-        const int ctx = cdv & 1023, maxlev = (int)((cdv >> 10) & 63) - 1;
-        const int x0 = L.xq[k], x1 = L.xq[k + 1];
-        const int a0 = x0 < 0 ? -x0 : x0, b0 = x1 < 0 ? -x1 : x1;
-        for (int lev = 0; lev < maxlev; lev++) {
-            const int pki = lc3t_ac_ctx_lut[ctx + imin(lev, 3) * 1024];
-            const uint16_t* cfp = &lc3t_ac_cum[pki * 18];
-            ac_encode(w, cfp[17] - cfp[16], cfp[16]);
-            const int b1 = (a0 >> lev) & 1, b2 = (b0 >> lev) & 1;
-            if (lsbMode == 1 && lev == 0) { lsb1 = b1; lsb2 = b2; }
-            else { put_bit_back(w, b1); put_bit_back(w, b2); }
-        }
-        const uint32_t cfv = L.cf[k >> 1];
-        ac_encode(w, (int)(cfv >> 16), (int)(cfv & 0xffff));
-        int a = a0, b = b0;
-        if (lsbMode == 1 && maxlev > 0) {
-#define PUSH_LSB(bitv) do { int bb = (bitv); if (bb) lsbs[nl >> 3] |= (uint8_t)(1 << (nl & 7)); nl++; } while (0)
-            a >>= 1; PUSH_LSB(lsb1);
-            if (a == 0 && x0 != 0) PUSH_LSB(x0 < 0);
-            b >>= 1; PUSH_LSB(lsb2);
-            if (b == 0 && x1 != 0) PUSH_LSB(x1 < 0);
-#undef PUSH_LSB
-        }
-        if (a != 0) put_bit_back(w, x0 < 0);
-        if (b != 0) put_bit_back(w, x1 < 0);
-    }
-    const int total = C.total_bits;
-    const int nbits_side = total - (8 * (w.bp_side + 1) + 8 - ilog2((unsigned)w.mask_side));
-    int nbits_ari = (w.bp + 1) * 8 + 25 - flog2f_int((unsigned)w.range);
-    if (w.cache >= 0) nbits_ari += 8;
-    if (w.carry_count > 0) nbits_ari += w.carry_count * 8;
-    int nres_enc = total - (nbits_side + nbits_ari);
-    nres_enc = imin(nres_enc, lsbMode == 0 ? nres : nl);
-    for (int k = 0; k < nres_enc; k++) put_bit_back(w, (L.res[k >> 3] >> (k & 7)) & 1);
-    ac_finish(w);
-}
 
 /* ------------------------------------------------------------------------------------------------ */
 /* the kernel: one wave per channel-stream, frames in time order  (frame driver R/enc_lc3_fl.c:13-160) */
@@ -1526,125 +1758,138 @@ lc3_encode_kernel(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__
     const int lane = threadIdx.x;
     const int cs = blockIdx.x;
     if (cs >= ncs) return;
-    const lc3d_chan C = chans[cs];
-    const int N = P->N, channels = P->channels;
+    const lc3d_chan* __restrict__ C = &chans[cs];
+    const int N = P->N, channels = P->channels, ml = N - P->la;
     const int strm = cs / channels, ch = cs - strm * channels;
 
     /* ---- load cross-frame state ---- */
     float* stp = state + (size_t)cs * LC3D_STATE_WORDS;
-    for (int i = lane; i < MAXN; i += WAVE) L.xbuf[i] = stp[LC3D_ST_XPREV + i];
+    for (int i = lane; i < MEMCAP; i += WAVE) L.xbuf[i] = stp[LC3D_ST_XPREV + i];
     for (int i = lane; i < 384; i += WAVE) L.h12[i] = stp[LC3D_ST_H12 + i];
     for (int i = lane; i < 194; i += WAVE) L.h6[i] = stp[LC3D_ST_H6 + i];
-    Scal S;
-    {
-        const float* sc = stp + LC3D_ST_SCAL; const int* si = (const int*)sc;
-        S.hp0 = sc[LC3D_S_HP0]; S.hp1 = sc[LC3D_S_HP1]; S.olpa_pitch = si[LC3D_S_OLPA_PITCH];
-        S.ltpf_nc1 = sc[LC3D_S_LTPF_NC1]; S.ltpf_nc2 = sc[LC3D_S_LTPF_NC2]; S.ltpf_pitch = sc[LC3D_S_LTPF_PITCH]; S.ltpf_on = si[LC3D_S_LTPF_ON];
-        S.att_m0 = sc[LC3D_S_ATT_M0]; S.att_m1 = sc[LC3D_S_ATT_M1]; S.att_acc = sc[LC3D_S_ATT_ACC];
-        S.att_pos = si[LC3D_S_ATT_POS]; S.att_flag = si[LC3D_S_ATT_FLAG];
-        S.tbits_off = sc[LC3D_S_TBITS_OFF]; S.mem_target = si[LC3D_S_MEM_TARGET]; S.mem_spec = si[LC3D_S_MEM_SPEC];
-        if (C.reset_attack) { S.att_m0 = S.att_m1 = S.att_acc = 0; S.att_pos = 0; S.att_flag = 0; }
-    }
+    if (lane < 16) L.fsc[lane] = stp[LC3D_ST_SCAL + lane];
+    if (lane < 16) L.isc[lane] = ((const int*)stp)[LC3D_ST_SCAL + 16 + lane];
     LSYNC();
+    if (C->reset_attack && lane == 0) { L.fsc[F_ATT_M0] = 0; L.fsc[F_ATT_M1] = 0; L.fsc[F_ATT_ACC] = 0; L.isc[I_ATT_POS] = 0; L.isc[I_ATT_FLAG] = 0; }
+    LSYNC();
+#ifdef LC3_STAGE_TIMING
+    if (lane < NSTAGE) L.tacc[lane] = 0;
+    LSYNC();
+    long long tlast = clock64();
+#endif
 
     for (int t = 0; t < T; t++) {
+#ifdef LC3_STAGE_TIMING
+        lc3d_trace* tr = nullptr;
+#else
         lc3d_trace* tr = trace ? &trace[(size_t)cs * T + t] : nullptr;
+#endif
         /* ---- PCM in (R/enc_lc3_fl.c:30-42) ---- */
         const size_t fidx = ((size_t)strm * T + t) * channels + ch;
         if (bitdepth == 16) {
             const int16_t* p = (const int16_t*)pcm + fidx * N;
-            for (int i = lane; i < N; i += WAVE) L.xbuf[MAXN + i] = (float)p[i];
+            for (int i = lane; i < N; i += WAVE) XCUR(L)[i] = (float)p[i];
         } else {
             const int32_t* p = (const int32_t*)pcm + fidx * N;
             const float sc = bitdepth == 24 ? 256.0f : 65536.0f;
-            for (int i = lane; i < N; i += WAVE) L.xbuf[MAXN + i] = (float)p[i] / sc;
+            for (int i = lane; i < N; i += WAVE) XCUR(L)[i] = (float)p[i] / sc;
         }
         for (int i = lane; i < 104; i += WAVE) ((uint32_t*)L.bytes)[i] = 0;
         LSYNC();
+        TICK(0);
 
-        st_mdct(P, L, lane);
-        if (tr) for (int i = lane; i < N; i += WAVE) tr->spec_mdct[i] = L.spec[i];
-        st_resample(P, L, S, lane);
+        st_resample(P, L, lane);
+        TICK(2);
         if (tr) for (int i = lane; i < P->len12 + 1; i += WAVE) tr->s12k8[i] = L.h12[384 - P->len12 - 24 + i];
-        int T0; float nc;
-        st_olpa(P, L, S, lane, T0, nc);
-        int ltpf[3], ltpf_bits;
-        st_ltpf(P, C, L, S, lane, T0, nc, ltpf, ltpf_bits);
-        st_attack(P, C, L, S, lane);
-        int bw = st_energy_bw(P, L, lane);
-        if (tr) { if (lane == 0) { tr->T0 = T0; tr->normcorr = nc; tr->ltpf_param[0] = ltpf[0]; tr->ltpf_param[1] = ltpf[1]; tr->ltpf_param[2] = ltpf[2];
-                                   tr->ltpf_bits = ltpf_bits; tr->attack = S.att_flag; }
+        st_olpa(P, L, lane);
+        TICK(3);
+        st_ltpf(P, C, L, lane);
+        TICK(4);
+        if (C->attack_handling) st_attack(P, L, lane);
+        TICK(5);
+        st_mdct(P, L, lane);
+        TICK(1);
+        if (tr) for (int i = lane; i < N; i += WAVE) tr->spec_mdct[i] = L.A[i];
+        st_energy_bw(P, L, lane);
+        TICK(6);
+        if (tr) { if (lane == 0) { tr->T0 = L.isc[I_T0]; tr->normcorr = L.fsc[F_NC]; tr->ltpf_param[0] = L.isc[I_LTPF0]; tr->ltpf_param[1] = L.isc[I_LTPF1];
+                                   tr->ltpf_param[2] = L.isc[I_LTPF2]; tr->ltpf_bits = L.isc[I_LTPF_BITS]; tr->attack = L.isc[I_ATT_FLAG]; }
                   tr->ener[lane] = lane < P->nbands ? L.sm[SM_ENER + lane] : 0; }
         LSYNC();
-        st_sns_scf(P, L, lane, S.att_flag);
+        st_sns_scf(P, L, lane);
+        TICK(7);
         if (tr && lane < 16) tr->scf[lane] = L.sm[SM_SCF + lane];
         st_sns_vq(P, L, lane);
+        TICK(8);
         st_sns_apply(P, L, lane);
+        TICK(9);
         if (tr) { if (lane < 16) tr->scf_q[lane] = L.sm[SM_SCFQ + lane]; if (lane < 7) tr->scf_idx[lane] = L.isc[I_SCF0 + lane];
-                  for (int i = lane; i < N; i += WAVE) tr->spec_shaped[i] = L.spec[i]; }
-        if (C.bandwidth) {                                  /* R/cutoff_bandwidth.c:13-26 */
-            const int bin = C.bw_cut_bin;
+                  for (int i = lane; i < N; i += WAVE) tr->spec_shaped[i] = L.A[i]; }
+        int bw = uni(L.isc[I_BW]);
+        if (C->bandwidth) {                                  /* R/cutoff_bandwidth.c:13-26 */
+            const int bin = C->bw_cut_bin;
             if (P->ylen > bin) {
-                if (lane < 4) { const float sc4[4] = {0.5f, 0.25f, 0.125f, 0.0625f}; L.spec[bin - 1 + lane] = L.spec[bin - 1 + lane] * sc4[lane]; }
-                for (int i = bin + 3 + lane; i < P->ylen; i += WAVE) L.spec[i] = 0;
+                if (lane < 4) { const float sc4[4] = {0.5f, 0.25f, 0.125f, 0.0625f}; L.A[bin - 1 + lane] = L.A[bin - 1 + lane] * sc4[lane]; }
+                for (int i = bin + 3 + lane; i < P->ylen; i += WAVE) L.A[i] = 0;
             }
-            bw = imin(bw, C.bw_index);
-            LSYNC();
+            bw = imin(bw, C->bw_index);
+            if (lane == 0) L.isc[I_BW] = bw;
         }
         const int bw_bin = lc3t_bw_bins[P->bw_cls * 6 + bw];
         if (lane < 16) L.isc[I_TNS_IDX0 + lane] = 0;
         if (lane < 2) L.isc[I_TNS_ORD0 + lane] = 0;
-        if (lane == 0) { L.isc[I_LTPF0] = ltpf[0]; L.isc[I_LTPF1] = ltpf[1]; L.isc[I_LTPF2] = ltpf[2]; }
         LSYNC();
         st_tns(P, C, L, lane, bw, bw_bin);
-        const int tns_bits = L.isc[I_TNS_BITS];
+        TICK(10);
+        const int tns_bits = uni(L.isc[I_TNS_BITS]);
         if (tr) { if (lane == 0) { tr->bw_idx = bw; tr->tns_nfilt = L.isc[I_TNS_NF]; tr->tns_order[0] = L.isc[I_TNS_ORD0]; tr->tns_order[1] = L.isc[I_TNS_ORD1]; tr->tns_bits = tns_bits; }
                   if (lane < 16) tr->tns_rc_idx[lane] = L.isc[I_TNS_IDX0 + lane];
-                  for (int i = lane; i < N; i += WAVE) tr->spec_tns[i] = L.spec[i]; }
-        const int tbq = C.target_bits_init - (tns_bits + ltpf_bits);
-        float gain; int gg, ggmin, nbits, nbits2, lastnz, lsb, change;
-        st_gain_estimate(P, C, L, S, lane, tbq, gain, gg, ggmin);
-        if (tr && lane == 0) { tr->target_bits_quant = tbq; tr->gain0 = gain; tr->gg_idx0 = gg; tr->gg_min = ggmin; }
-        st_quantize(P, C, L, lane, gain, -1, tbq, nbits, nbits2, lastnz, lsb);
-        S.mem_spec = nbits;
-        if (tr && lane == 0) tr->nbits0 = nbits;
-        st_gain_adjust(P, C, gg, ggmin, gain, tbq, nbits, change);
-        if (change) st_quantize(P, C, L, lane, gain, 0, tbq, nbits, nbits2, lastnz, lsb);
-        const int fac_ns = st_noise_factor(P, C, L, lane, gain, bw_bin);
-        int nres = 0;
-        if (lsb == 0) nres = st_residual(P, L, lane, gain, tbq, nbits2);
-        else { for (int i = lane; i < 160; i += WAVE) ((uint32_t*)L.res)[i] = 0; }
+                  for (int i = lane; i < N; i += WAVE) tr->spec_tns[i] = L.A[i]; }
+        const int tbq = C->target_bits_init - (tns_bits + uni(L.isc[I_LTPF_BITS]));
+        st_gain_estimate(P, C, L, lane, tbq);
+        TICK(11);
+        if (tr && lane == 0) { tr->target_bits_quant = tbq; tr->gain0 = L.fsc[F_GAIN]; tr->gg_idx0 = L.isc[I_GG]; tr->gg_min = L.isc[I_GGMIN]; }
+        st_quantize(P, C, L, lane, -1, tbq);
+        TICK(12);
+        {
+            int gg = uni(L.isc[I_GG]), change; float gain = unif(L.fsc[F_GAIN]);
+            const int nbits0 = uni(L.isc[I_NBITS]);
+            if (tr && lane == 0) tr->nbits0 = nbits0;
+            gain_adjust(P, C, gg, uni(L.isc[I_GGMIN]), gain, tbq, nbits0, change);
+            LSYNC();
+            if (lane == 0) { L.isc[I_MEM_SPEC] = nbits0; L.isc[I_GG] = gg; L.fsc[F_GAIN] = gain; L.isc[I_CHANGE] = change; }
+            LSYNC();
+            if (change) st_quantize(P, C, L, lane, 0, tbq);
+        }
+        TICK(13);
+        st_noise_factor(P, C, L, lane, bw_bin);
+        TICK(14);
+        if (tr) { if (lane == 0) { tr->gain = L.fsc[F_GAIN]; tr->gg_idx = L.isc[I_GG]; tr->gain_change = L.isc[I_CHANGE]; tr->nbits = L.isc[I_NBITS]; tr->nbits2 = L.isc[I_NBITS2];
+                                   tr->lastnz = L.isc[I_LASTNZ]; tr->lsb_mode = L.isc[I_LSB]; tr->fac_ns = L.isc[I_FACNS]; }
+                  for (int i = lane; i < N; i += WAVE) tr->xq[i] = i < P->ylen ? XQ(L)[i] : 0; }
+        if (uni(L.isc[I_LSB]) == 0) st_residual(P, L, lane, tbq, uni(L.isc[I_NBITS2]));
+        else { for (int i = lane; i < 160; i += WAVE) ((uint32_t*)RESB(L))[i] = 0; if (lane == 0) L.isc[I_NRES] = 0; LSYNC(); }
+        TICK(15);
+        st_bitstream(P, C, L, lane);
         LSYNC();
-        if (tr) { if (lane == 0) { tr->gain = gain; tr->gg_idx = gg; tr->gain_change = change; tr->nbits = nbits; tr->nbits2 = nbits2; tr->lastnz = lastnz;
-                                   tr->lsb_mode = lsb; tr->fac_ns = fac_ns; tr->n_res_bits = nres; }
-                  for (int i = lane; i < N; i += WAVE) tr->xq[i] = i < P->ylen ? L.xq[i] : 0; }
-        if (lane == 0) st_bitstream(P, C, L, bw, lastnz, lsb, gg, fac_ns, nres, tr ? &tr->bp_side : nullptr, tr ? &tr->mask_side : nullptr);
-        LSYNC();
+        TICK(16);
+        if (tr && lane == 0) { tr->n_res_bits = L.isc[I_NRES]; tr->bp_side = L.isc[I_BP_SIDE]; tr->mask_side = L.isc[I_MASK_SIDE]; }
         /* ---- bytes out ---- */
-        uint8_t* o = out + ((size_t)strm * T + t) * out_stride + C.out_off;
-        for (int i = lane; i < C.nbytes; i += WAVE) o[i] = L.bytes[i];
-        /* ---- slide the input history ---- */
-        float keep[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) { int i = lane + 64 * k; keep[k] = i < N ? L.xbuf[MAXN + i] : 0.0f; }
+        uint8_t* o = out + ((size_t)strm * T + t) * out_stride + C->out_off;
+        for (int i = lane; i < C->nbytes; i += WAVE) o[i] = L.bytes[i];
         LSYNC();
-#pragma unroll
-        for (int k = 0; k < 8; k++) { int i = lane + 64 * k; if (i < N) L.xbuf[MAXN - N + i] = keep[k]; }
-        LSYNC();
+        TICK(17);
     }
-
+#ifdef LC3_STAGE_TIMING
+    if (trace && lane < NSTAGE) ((long long*)&trace[(size_t)cs * T])[lane] = L.tacc[lane];
+#endif
     /* ---- store cross-frame state ---- */
-    for (int i = lane; i < MAXN; i += WAVE) stp[LC3D_ST_XPREV + i] = L.xbuf[i];
+    for (int i = lane; i < MEMCAP; i += WAVE) stp[LC3D_ST_XPREV + i] = L.xbuf[i];
     for (int i = lane; i < 384; i += WAVE) stp[LC3D_ST_H12 + i] = L.h12[i];
     for (int i = lane; i < 194; i += WAVE) stp[LC3D_ST_H6 + i] = L.h6[i];
-    if (lane == 0) {
-        float* sc = stp + LC3D_ST_SCAL; int* si = (int*)sc;
-        sc[LC3D_S_HP0] = S.hp0; sc[LC3D_S_HP1] = S.hp1; si[LC3D_S_OLPA_PITCH] = S.olpa_pitch;
-        sc[LC3D_S_LTPF_NC1] = S.ltpf_nc1; sc[LC3D_S_LTPF_NC2] = S.ltpf_nc2; sc[LC3D_S_LTPF_PITCH] = S.ltpf_pitch; si[LC3D_S_LTPF_ON] = S.ltpf_on;
-        sc[LC3D_S_ATT_M0] = S.att_m0; sc[LC3D_S_ATT_M1] = S.att_m1; sc[LC3D_S_ATT_ACC] = S.att_acc;
-        si[LC3D_S_ATT_POS] = S.att_pos; si[LC3D_S_ATT_FLAG] = S.att_flag;
-        sc[LC3D_S_TBITS_OFF] = S.tbits_off; si[LC3D_S_MEM_TARGET] = S.mem_target; si[LC3D_S_MEM_SPEC] = S.mem_spec;
-    }
+    if (lane < 16) stp[LC3D_ST_SCAL + lane] = L.fsc[lane];
+    if (lane < 16) ((int*)stp)[LC3D_ST_SCAL + 16 + lane] = L.isc[lane];
+    (void)ml;
 }
 
 /* ------------------------------------------------------------------------------------------------ */

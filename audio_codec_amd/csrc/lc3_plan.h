@@ -27,6 +27,8 @@ typedef struct {
     float   c_2m32, c_2m31, c_2m24, c_2p15, c_2p100;
     float   c_sqrt2;            /* sqrtf(2) */
     float   c_idct_n1, c_idct_n2;   /* R/sns_quantize_scf.c:24-25 */
+    float   c_thr7_up;          /* smallest float >= (7.0)*(28.0/20.0):  (double)t < thr  <=>  t < c_thr7_up  (R/estimate_global_gain.c:106) */
+    float   c_thr50_dn;         /* largest float <= (50.0)*(28.0/20.0): (double)t > thr  <=>  t > c_thr50_dn (R/estimate_global_gain.c:111) */
     float   pad0;
     float   tw1[LC3D_MAX_N], tw2[LC3D_MAX_N];      /* N/2 complex (re,im) pairs each */
     float   dct2_tw[32];
@@ -48,15 +50,13 @@ typedef struct {
 } lc3d_chan;
 
 /* ---- state layout (32-bit words) ---- */
-#define LC3D_ST_XPREV   0                         /* previous frame's input samples as float [LC3D_MAX_N] */
-#define LC3D_ST_H12     (LC3D_ST_XPREV + LC3D_MAX_N)   /* last 384 samples of the HP-filtered 12.8 kHz stream */
+#define LC3D_ST_XPREV   0                         /* MDCT / resampler memory: tail of the previous frame, right-aligned in 300 words */
+#define LC3D_ST_H12     (LC3D_ST_XPREV + 300)   /* last 384 samples of the HP-filtered 12.8 kHz stream */
 #define LC3D_H12_KEEP   384
 #define LC3D_ST_H6      (LC3D_ST_H12 + LC3D_H12_KEEP)  /* last 194 samples of the 6.4 kHz stream */
 #define LC3D_H6_KEEP    194
-#define LC3D_ST_SCAL    (LC3D_ST_H6 + LC3D_H6_KEEP + 2)
-enum { LC3D_S_HP0 = 0, LC3D_S_HP1, LC3D_S_OLPA_PITCH, LC3D_S_LTPF_NC1, LC3D_S_LTPF_NC2, LC3D_S_LTPF_PITCH, LC3D_S_LTPF_ON,
-       LC3D_S_ATT_M0, LC3D_S_ATT_M1, LC3D_S_ATT_ACC, LC3D_S_ATT_POS, LC3D_S_ATT_FLAG, LC3D_S_TBITS_OFF, LC3D_S_MEM_TARGET,
-       LC3D_S_MEM_SPEC, LC3D_S_COUNT };
-#define LC3D_STATE_WORDS 1088
+#define LC3D_ST_SCAL    (LC3D_ST_H6 + LC3D_H6_KEEP + 2)   /* 16 float scalars (kernel fsc[0..15]) then 16 int scalars (isc[0..15]) */
+#define LC3D_S_OLPA_PITCH_WORD (LC3D_ST_SCAL + 16 + 0) /* isc[I_OLPA_PITCH]: initial value 17 (R/setup_enc_lc3.c:178) */
+#define LC3D_STATE_WORDS 960
 
 #endif

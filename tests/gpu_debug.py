@@ -55,7 +55,11 @@ def main():
                     m = fields_cmp(f, np.ctypeslib.as_array(ga)[:n], np.ctypeslib.as_array(ca)[:n])
                 else:
                     m = fields_cmp(f, [ga], [ca])
-                if m: msgs.append(m)
+                if m:
+                    msgs.append(m)
+                    if os.environ.get('DBG_FULL') and hasattr(ga, '__len__') and len(ga) <= 64:
+                        msgs.append('   gpu ' + np.array2string(np.ctypeslib.as_array(ga), precision=5, max_line_width=200))
+                        msgs.append('   cpu ' + np.array2string(np.ctypeslib.as_array(ca), precision=5, max_line_width=200))
             if (not ok or msgs) and shown < 12:
                 shown += 1
                 print("stream %d frame %d bytes_ok=%s" % (streams[b], t, ok))

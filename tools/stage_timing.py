@@ -1,0 +1,26 @@
+"""Diagnostic: per-stage wave latency (shader cycles per frame) from the -DLC3_STAGE_TIMING build.
+Usage (GPU box): python tools/stage_timing.py [B T bitrate]"""
+import ctypes as C, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import audio_codec_amd.api as api
+api.lib_path = lambda: os.path.join(ROOT, "audio_codec_amd", "liblc3plus_hip_timing.so")
+from lc3_harness import synth_pcm
+NAMES = ["load", "mdct", "resample", "olpa", "ltpf", "attack", "energy_bw", "sns_scf", "sns_vq", "sns_apply", "tns", "gain_est",
+         "quant1", "gain_adj+quant2", "noise", "residual", "bitstream", "store+slide"]
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+T = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+br = int(sys.argv[3]) if len(sys.argv) > 3 else 64000
+pcm = synth_pcm(B, T, 480, 48000, seed=3)
+b = api.Batch(B, 48000, 1, 10.0, 0, [br] * B, device=0)
+out, tr = b.encode_traced(pcm)
+tsz = tr.shape[1]
+acc = np.zeros(24)
+for s in range(B):
+    acc += np.frombuffer(tr[s * T].tobytes()[:24 * 8], dtype=np.int64)
+acc = acc / (B * T)
+tot = acc.sum()
+print("kernel %.3f ms for %d streams x %d frames; mean cycles/frame/wave = %.0f" % (b.last_kernel_ms(), B, T, tot))
+for n, v in zip(NAMES, acc):
+    print("  %-16s %10.0f  %5.1f %%" % (n, v, 100 * v / tot))
