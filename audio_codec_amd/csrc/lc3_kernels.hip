@@ -22,6 +22,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <stddef.h>
 
 #define LC3T_QUAL static __device__ const
 #include "lc3_tables.h"
@@ -54,6 +55,9 @@ struct __attribute__((aligned(16))) WaveLds {
     float h12[384];             /* HP-filtered 12.8 kHz stream, newest sample at [383] */
     float h6[196];              /* 6.4 kHz stream, newest at [193] */
     float sm[704];              /* small vectors (SM_*); from quantisation on: cd[240] | cf[240] | zero-line list / residual bits */
+    int   pc[48];               /* the scalar head of the plan (lc3d_plan up to pad0), copied once: stage code reads it from LDS
+                                   instead of through a flat pointer, and readfirstlane makes the values scalar */
+    int   cc[16];               /* this channel-stream's lc3d_chan */
     float fsc[16];              /* float scalars: cross-frame state + values passed between stages */
     int   isc[80];              /* integer scalars */
     uint8_t bytes[416];         /* the output frame */
@@ -61,6 +65,9 @@ struct __attribute__((aligned(16))) WaveLds {
     long long tacc[NSTAGE];
 #endif
 };
+#define PI(f) uni(L.pc[offsetof(lc3d_plan, f) / 4])
+#define PF(f) __int_as_float(uni(L.pc[offsetof(lc3d_plan, f) / 4]))
+#define CI(f) uni(L.cc[offsetof(lc3d_chan, f) / 4])
 #define XCUR(L) (&(L).xbuf[MEMCAP])
 #define XQ(L)   ((int*)&(L).xbuf[MEMCAP])
 #define SPEC(L) ((L).A)
@@ -296,8 +303,8 @@ __device__ __forceinline__ double rl_d(double v, int l)
 /* ---- 12.8 kHz resampler + 50 Hz high-pass: R/resamp12k8.c:13-84.  Appends len12 samples to h12. ---- */
 STAGE void st_resample(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
 {
-    const int mlen = P->rs_mem_in_len, stride = P->rs_stride, n12 = P->n12, len12 = P->len12;
-    const float sf = P->rs_scale;
+    const int mlen = PI(rs_mem_in_len), stride = PI(rs_stride), n12 = PI(n12), len12 = PI(len12);
+    const float sf = PF(rs_scale);
     const float* buf = &L.xbuf[MEMCAP - mlen];      /* [mem_in | x] */
     float d[2] = {0, 0};
 #pragma unroll
@@ -358,9 +365,9 @@ __device__ __forceinline__ float olpa_normcorr(const float* s6, int acf, int T, 
 /* ---- open-loop pitch: R/olpa.c:52-143 ---- */
 STAGE void st_olpa(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
 {
-    const int len = P->len12, len2 = len >> 1;
+    const int len = PI(len12), len2 = len >> 1;
     int acf = len2, back = 0;
-    if (P->dms == 25) { acf += 16; back = 16; }
+    if (PI(dms) == 25) { acf += 16; back = 16; }
     float nd = 0;
     if (lane < len2) {                              /* 2:1 decimation (filter_olpa R/olpa.c:16-31) */
         const float* in12 = &L.h12[384 - len - 27];
@@ -392,14 +399,14 @@ STAGE void st_olpa(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
     wave_argmax_first(best, besti, 64);
     int T0 = uni(besti) + 17;
     LSYNC();
-    float nc = olpa_normcorr(s6, acf, T0, lane, P->c_1em5_a);
+    float nc = olpa_normcorr(s6, acf, T0, lane, PF(c_1em5_a));
     const int old = uni(L.isc[I_OLPA_PITCH]);
     const int lo = imax(17, old - 4), hi = imin(114, old + 4), cnt = hi - lo + 1;
     float v = (lane & 15) < cnt ? R0[lo - 17 + (lane & 15)] : -INFINITY; int vi = lane & 15;
     wave_argmax_first(v, vi, 16);
     const int T02 = uni(vi) + lo;
     if (T02 != T0) {
-        const float nc2 = olpa_normcorr(s6, acf, T02, lane, P->c_1em5_a);
+        const float nc2 = olpa_normcorr(s6, acf, T02, lane, PF(c_1em5_a));
         if ((double)nc2 > ((double)nc * 0.85)) { T0 = T02; nc = nc2; }
     }
     if (lane == 0) { L.isc[I_OLPA_PITCH] = T0; L.isc[I_T0] = (int)(T0 * 2.0); L.fsc[F_NC] = nc; }
@@ -409,7 +416,7 @@ STAGE void st_olpa(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
 /* ---- LTPF parameter coder: R/ltpf_coder.c:34-263 ---- */
 STAGE void st_ltpf(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ C, WaveLds& L, int lane)
 {
-    const int len = P->len12;                 /* N of the reference = xLen - 1 */
+    const int len = PI(len12);                 /* N of the reference = xLen - 1 */
     const float* x = &L.h12[384 - len - 24];
     const int pitch_ol = uni(L.isc[I_T0]); const float ol_nc = unif(L.fsc[F_NC]);
     const int mem_on = uni(L.isc[I_LTPF_ON]);
@@ -419,7 +426,7 @@ STAGE void st_ltpf(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict_
     if ((double)ol_nc > 0.6) {
         const int t0_min = imax(pitch_ol - 4, 32), t0_max = imin(pitch_ol + 4, 228);
         int acf = len;
-        if (P->dms == 25) { acf = 2 * len; x = x - len; }
+        if (PI(dms) == 25) { acf = 2 * len; x = x - len; }
         const int t_min = t0_min - 4, t_max = t0_max + 4, nl = t_max - t_min + 1;
         float sum1 = 0, sum2 = 0;
         {   /* R/ltpf_coder.c:74-78: two serial sums over acf <= 128 terms, products per lane */
@@ -442,7 +449,7 @@ STAGE void st_ltpf(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict_
             for (int j = 0; j < acf; j++) sum += x[j] * xl[j];
             float s2 = sum2;
             for (int k = t_min + 1; k <= lag; k++) s2 = s2 + x[-k] * x[-k] - x[acf - 1 - (k - 1)] * x[acf - 1 - (k - 1)];
-            const float sum3 = sqrtf(sum1 * s2) + P->c_1em5_b;
+            const float sum3 = sqrtf(sum1 * s2) + PF(c_1em5_b);
             float nc = sum / sum3;
             nc = 0 > nc ? 0 : nc;
             cor[lane] = nc;
@@ -493,12 +500,12 @@ STAGE void st_ltpf(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict_
             const int cnt = imin(acf - 64 * h, 64);
             for (int i = 0; i < cnt; i++) { a += rl_f(pa, i); b += rl_f(pb, i); c += rl_f(pc, i); }
         }
-        b = sqrtf(b * c) + P->c_1em5_b;
+        b = sqrtf(b * c) + PF(c_1em5_b);
         norm_corr = a / b;
         { const float lo = -1 > norm_corr ? -1 : norm_corr; norm_corr = 1 < lo ? 1 : lo; }
         if (norm_corr < 0) norm_corr = 0;
-        if (C->ltpf_enable == 1) {
-            if ((mem_on == 0 && (P->dms == 100 || (double)nc2m > 0.94) && (double)nc1 > 0.94 && (double)norm_corr > 0.94) ||
+        if (CI(ltpf_enable) == 1) {
+            if ((mem_on == 0 && (PI(dms) == 100 || (double)nc2m > 0.94) && (double)nc1 > 0.94 && (double)norm_corr > 0.94) ||
                 (mem_on == 1 && (double)norm_corr > 0.9) ||
                 (mem_on == 1 && fabsf(pitch - mem_pitch) < 2 && (double)(norm_corr - nc1) > -0.1 && (double)norm_corr > 0.84))
                 active = 1;
@@ -509,7 +516,7 @@ STAGE void st_ltpf(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict_
     if (lane == 0) {
         if (gain > 0) { L.isc[I_LTPF0] = 1; L.isc[I_LTPF1] = active; L.isc[I_LTPF2] = pitch_index; L.isc[I_LTPF_BITS] = 11; }
         else { L.isc[I_LTPF0] = 0; L.isc[I_LTPF1] = 0; L.isc[I_LTPF2] = 0; L.isc[I_LTPF_BITS] = 1; }
-        if (P->dms < 100) L.fsc[F_LTPF_NC2] = nc1;
+        if (PI(dms) < 100) L.fsc[F_LTPF_NC2] = nc1;
         L.fsc[F_LTPF_NC1] = norm_corr; L.isc[I_LTPF_ON] = active; L.fsc[F_LTPF_PITCH] = pitch;
     }
     LSYNC();
@@ -518,19 +525,19 @@ STAGE void st_ltpf(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict_
 /* ---- attack detector: R/attack_detector.c:13-104 (only when attack_handling) ---- */
 STAGE void st_attack(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
 {
-    const int nb = P->att_nblocks, n16 = nb * 40;
+    const int nb = PI(att_nblocks), n16 = nb * 40;
     const float* in = XCUR(L);
     float* p = &L.A[2];
     float mval = 0;
     for (int j = lane; j < n16; j += WAVE) {
         float v;
-        if (P->fs == 96000) { const float* q = &in[6 * j]; v = q[0] + q[1] + q[2] + q[3] + q[4] + q[5]; }
-        else if (P->fs == 48000) { const float* q = &in[3 * j]; v = (q[0] + q[1] + q[2]); }
-        else if (P->fs == 32000) { const float* q = &in[2 * j]; v = (q[0] + q[1]); }
+        if (PI(fs) == 96000) { const float* q = &in[6 * j]; v = q[0] + q[1] + q[2] + q[3] + q[4] + q[5]; }
+        else if (PI(fs) == 48000) { const float* q = &in[3 * j]; v = (q[0] + q[1] + q[2]); }
+        else if (PI(fs) == 32000) { const float* q = &in[2 * j]; v = (q[0] + q[1]); }
         else { const float* q = &in[3 * j]; v = (float)((double)q[0] + ((double)(q[1] + q[2])) / 2.0); }
         p[j] = v;
     }
-    if (P->fs == 96000) mval = 1e-5f;
+    if (PI(fs) == 96000) mval = 1e-5f;
     if (lane == 0) { p[-2] = L.fsc[F_ATT_M0]; p[-1] = L.fsc[F_ATT_M1]; }
     LSYNC();
     const float nm0 = p[n16 - 2], nm1 = p[n16 - 1];
@@ -554,7 +561,7 @@ STAGE void st_attack(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
         const double q = 0.25 * (double)acc;
         acc = (double)nrg > q ? nrg : (float)q;
     }
-    if (uni(L.isc[I_ATT_POS]) > P->att_hang) flag = 1;
+    if (uni(L.isc[I_ATT_POS]) > PI(att_hang)) flag = 1;
     LSYNC();
     if (lane == 0) { L.fsc[F_ATT_M0] = nm0; L.fsc[F_ATT_M1] = nm1; L.fsc[F_ATT_ACC] = acc; L.isc[I_ATT_FLAG] = flag; L.isc[I_ATT_POS] = pos; }
     LSYNC();
@@ -620,8 +627,8 @@ STAGE void mdct_dft120(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)   
 }
 STAGE void st_mdct(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
 {
-    const int N = P->N, h = N >> 1, la = P->la;
-    const float* w = &lc3t_win_pool[P->win_off];
+    const int N = PI(N), h = N >> 1, la = PI(la);
+    const float* w = &lc3t_win_pool[PI(win_off)];
     const float* t = &L.xbuf[MEMCAP - (N - la)];    /* t[j] = [memory | frame], j < 2N-la ; zero beyond */
     const int lim = 2 * N - la;
     for (int i = lane; i < h; i += WAVE) {
@@ -642,7 +649,7 @@ STAGE void st_mdct(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
     LSYNC();
     if (h == 240) { mdct_dft240_cols(L, lane); mdct_dft240_rows(L, lane); }
     else mdct_dft120(P, L, lane);
-    const float norm = P->dct4_norm;
+    const float norm = PF(dct4_norm);
     for (int i = lane; i < h; i += WAVE) {          /* post-twiddle R/dct4.c:90-94; the spectrum lands in A */
         const float ar = L.B[2 * i], ai = L.B[2 * i + 1], br = P->tw2[2 * i], bi = P->tw2[2 * i + 1];
         const float tr = ar * br - ai * bi, ti = ai * br + ar * bi;
@@ -663,19 +670,19 @@ STAGE void st_mdct(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
 /* ---- per-band energy R/per_band_energy.c:13-30, bandwidth detector R/detect_cutoff_warped.c:13-83 ---- */
 STAGE void st_energy_bw(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
 {
-    const uint16_t* be = &lc3t_band_pool[P->band_off];
+    const uint16_t* be = &lc3t_band_pool[PI(band_off)];
     float* en = &L.sm[SM_ENER];
-    if (lane < P->nbands) {
+    if (lane < PI(nbands)) {
         const int a = be[lane], b = be[lane + 1];
         float sum = 0;
         for (int j = a; j < b; j++) { const float v = L.A[j]; sum += v * v; }
         en[lane] = sum / (float)(b - a);
     }
     LSYNC();
-    int bw = P->fs_idx;
-    if (P->fs_idx > 0 && P->hrmode == 0) {
-        const int f = P->fs_idx;
-        const uint8_t* st = &lc3t_bw_start[(P->bw_cls * 4 + f - 1) * 4]; const uint8_t* sp = &lc3t_bw_stop[(P->bw_cls * 4 + f - 1) * 4];
+    int bw = PI(fs_idx);
+    if (PI(fs_idx) > 0 && PI(hrmode) == 0) {
+        const int f = PI(fs_idx);
+        const uint8_t* st = &lc3t_bw_start[(PI(bw_cls) * 4 + f - 1) * 4]; const uint8_t* sp = &lc3t_bw_stop[(PI(bw_cls) * 4 + f - 1) * 4];
         const float ev = en[lane];
         int counter = f;
         float sum = 0;
@@ -710,7 +717,7 @@ STAGE void st_sns_scf(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
 {
     float* x = &L.sm[SM_ENER];
     const int smooth = uni(L.isc[I_ATT_FLAG]);
-    int nb = P->nbands;
+    int nb = PI(nbands);
     float c = x[lane < nb ? lane : 0];
     if (nb < 64) {
         const int d = 64 - nb;
@@ -730,8 +737,8 @@ STAGE void st_sns_scf(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
     float sum = 0;
     for (int i = 0; i < 64; i++) sum += rl_f(s, i);
     float mean = sum / (float)64;
-    float nf = mean * P->c_1em4;
-    nf = nf > P->c_2m32 ? nf : P->c_2m32;
+    float nf = mean * PF(c_1em4);
+    nf = nf > PF(c_2m32) ? nf : PF(c_2m32);
     if (s < nf) s = nf;
     const float xl = (float)((double)m_log2f(s) / 2.0);
     float* tmp = &L.sm[SM_MISC];
@@ -753,7 +760,7 @@ STAGE void st_sns_scf(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
     sum = 0;
     for (int i = 0; i < 16; i++) sum += rl_f(v4, i);
     mean = (float)((double)sum / ((double)(float)nb / 4.0));
-    float g = P->sns_damping * (v4 - mean);
+    float g = PF(sns_damping) * (v4 - mean);
     if (smooth) {
         const float gm2 = __shfl_up(g, 2), gm1 = __shfl_up(g, 1), gp1 = __shfl_down(g, 1), gp2 = __shfl_down(g, 2);
         float gs;
@@ -765,14 +772,14 @@ STAGE void st_sns_scf(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
         sum = 0;
         for (int i = 0; i < 16; i++) sum += rl_f(gs, i);
         mean = sum / (float)16;
-        g = P->att_damping * (gs - mean);
+        g = PF(att_damping) * (gs - mean);
     }
     if (lane < 16) L.sm[SM_SCF + lane] = g;
     LSYNC();
 }
 
 /* ---- PVQ pulse search R/sns_quantize_scf.c:43-136: one search per lane, everything in registers ---- */
-__device__ __forceinline__ void pvq_search_reg(const lc3d_plan* __restrict__ P, const float* x_in, int dim, int pulses, int* y_out, float* yn_out)
+__device__ __forceinline__ void pvq_search_reg(WaveLds& L, const float* x_in, int dim, int pulses, int* y_out, float* yn_out)
 {
     float xabs[16]; int y[16];
     float xsum = 0, yy = 0, xy = 0;
@@ -780,7 +787,7 @@ __device__ __forceinline__ void pvq_search_reg(const lc3d_plan* __restrict__ P, 
     for (int i = 0; i < 16; i++) { xabs[i] = i < dim ? fabsf(x_in[i]) : 0.0f; y[i] = 0; }
 #pragma unroll
     for (int i = 0; i < 16; i++) if (i < dim) xsum += xabs[i];
-    if (xsum > P->c_2m24) {
+    if (xsum > PF(c_2m24)) {
         int tot = 0;
         const float proj = (float)(pulses - 1) / xsum;
 #pragma unroll
@@ -792,7 +799,7 @@ __device__ __forceinline__ void pvq_search_reg(const lc3d_plan* __restrict__ P, 
         }
         yy = yy * 0.5f;
         while (tot < pulses) {
-            int imx = 0; float cnum = -P->c_2p15, cden = 0;
+            int imx = 0; float cnum = -PF(c_2p15), cden = 0;
             yy = yy + 0.5f;
 #pragma unroll
             for (int i = 0; i < 16; i++) if (i < dim) {
@@ -862,7 +869,7 @@ STAGE void st_sns_vq(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
         float o = 0;
 #pragma unroll
         for (int i = 0; i < 16; i++) if (lane == i) o = z[2 * i] * P->dct2_tw[2 * i] - z[2 * i + 1] * P->dct2_tw[2 * i + 1];
-        if (lane == 0) o = o / P->c_sqrt2;
+        if (lane == 0) o = o / PF(c_sqrt2);
         if (lane < 16) tgt[lane] = o;
     }
     LSYNC();
@@ -870,7 +877,7 @@ STAGE void st_sns_vq(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
     float* pv = &L.sm[SM_PVQ];
     if (lane < 4) {
         const int dim = lane == 0 ? 10 : lane == 1 ? 6 : 16, K = lane == 0 ? 10 : lane == 1 ? 1 : lane == 2 ? 8 : 6;
-        pvq_search_reg(P, lane == 1 ? tgt + 10 : tgt, dim, K, (int*)(pv + lane * 32), pv + lane * 32 + 16);
+        pvq_search_reg(L, lane == 1 ? tgt + 10 : tgt, dim, K, (int*)(pv + lane * 32), pv + lane * 32 + 16);
     }
     LSYNC();
     const int* pA = (const int*)(pv); const int* pB = (const int*)(pv + 32);
@@ -894,7 +901,7 @@ STAGE void st_sns_vq(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
     {
         float err = INFINITY;
         if (lane < 6) { float s = 0; for (int j = 0; j < 16; j++) { const float d = tgt[j] - vec[lane * 16 + j]; s += d * d; } err = s; }
-        float min_err = P->c_2p15;
+        float min_err = PF(c_2p15);
         for (int i = 0; i < 6; i++) { const float e = rl_f(err, i); if (e < min_err) { min_err = e; idx = i; } }
         glob = lc3t_sns_gain_q[idx];
     }
@@ -910,10 +917,10 @@ STAGE void st_sns_vq(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
 #pragma unroll
         for (int j = 0; j < 16; j++) {
             float t = (float)((double)in[j] * P->idct_cos[i * 16 + j]);
-            if (j == 0) t *= P->c_idct_n2;
+            if (j == 0) t *= PF(c_idct_n2);
             sum += t;
         }
-        idc[48 + lane] = P->c_idct_n1 * sum;
+        idc[48 + lane] = PF(c_idct_n1) * sum;
     }
     LSYNC();
     const float* split = &idc[48]; const float* subN = &idc[64]; const float* subF = &idc[80];
@@ -929,17 +936,17 @@ STAGE void st_sns_vq(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
     }
     const float e_split = rl_f(err, 0);
     int sub_mode = 0, sub_gain = 0, shape = 0;    /* shape: 0 = yC, 1 = pA only, 2 = near, 3 = far */
-    float e_sofar = P->c_2p15, g_sel = 0; const float* v_sel = split;
+    float e_sofar = PF(c_2p15), g_sel = 0; const float* v_sel = split;
     bool have = false;
     if (e_split < e_sofar) {
         if (idx <= 1) { sub_mode = 0; sub_gain = idx; shape = 0; } else { sub_mode = 1; sub_gain = idx - 2; shape = 1; }
         g_sel = glob; v_sel = split; e_sofar = e_split; have = true;
     }
     {
-        float min_err = P->c_2p15; int gi = idx; float gg = glob;
+        float min_err = PF(c_2p15); int gi = idx; float gg = glob;
         for (int i = 0; i < 4; i++) { const float e = rl_f(err, 1 + i); if (e < min_err) { gi = i; min_err = e; gg = lc3t_sns_gain_near[i]; } }
         if (min_err < e_sofar) { sub_mode = 2; sub_gain = gi; shape = 2; g_sel = gg; v_sel = subN; e_sofar = min_err; have = true; }
-        min_err = P->c_2p15;
+        min_err = PF(c_2p15);
         for (int i = 0; i < 8; i++) { const float e = rl_f(err, 5 + i); if (e < min_err) { gi = i; min_err = e; gg = lc3t_sns_gain_far[i]; } }
         if (min_err < e_sofar) { sub_mode = 3; sub_gain = gi; shape = 3; g_sel = gg; v_sel = subF; have = true; }
     }
@@ -982,7 +989,7 @@ STAGE void st_sns_apply(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
         const double dd = (double)(g[15] - g[14]);
         v = lane == 62 ? (float)((double)g[15] + dd / 8.0) : (float)((double)g[15] + 3.0 * dd / 8.0);
     }
-    const int nb = P->nbands;
+    const int nb = PI(nbands);
     if (nb < 64) {
         gi[lane] = v;
         LSYNC();
@@ -1001,7 +1008,7 @@ STAGE void st_sns_apply(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
     }
     if (lane < nb) gi[lane] = m_powf(2.0f, -v);
     LSYNC();
-    for (int j = lane; j < P->N; j += WAVE) {
+    for (int j = lane; j < PI(N); j += WAVE) {
         const int b = P->band_of_bin[j];
         if (b < nb) L.A[j] = L.A[j] * gi[b];
     }
@@ -1013,10 +1020,10 @@ STAGE void st_sns_apply(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
 /* ------------------------------------------------------------------------------------------------ */
 struct TnsGeom { int numfilters, maxOrder, nSub, start[2], stop[2]; float maxPG; int obits_off; };
 
-__device__ __forceinline__ TnsGeom tns_geom(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ C, int bw_idx, int bw_bin)
+__device__ __forceinline__ TnsGeom tns_geom(WaveLds& L, int bw_idx, int bw_bin)
 {
     TnsGeom g;
-    int fs = P->fs, N = P->N; const int nBits = C->total_bits, dms = P->dms;
+    int fs = PI(fs), N = PI(N); const int nBits = CI(total_bits), dms = PI(dms);
     g.numfilters = (fs >= 32000 && dms >= 50) ? 2 : 1;
     g.start[0] = g.start[1] = g.stop[0] = g.stop[1] = 0;
     if ((double)N > 40 * ((double)(float)dms / 10.0)) { N = (int)(40 * ((double)(float)dms / 10.0)); fs = 40000; }
@@ -1181,7 +1188,7 @@ STAGE void tns_lattice(WaveLds& L, int lane, int b_first, int cnt, int ord)
 
 STAGE void st_tns(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ C, WaveLds& L, int lane, int bw_idx, int bw_bin)
 {
-    const TnsGeom G = tns_geom(P, C, bw_idx, bw_bin);
+    const TnsGeom G = tns_geom(L, bw_idx, bw_bin);
     float* racc = &L.sm[SM_MISC];              /* [f][sub][k] 2*3*9 = 54, sub-division energies 6 at +54, r[f][9] at +64 */
     {   /* one serial sum per lane: lanes 0..53 autocorrelation terms, 54..59 sub-division energies (R/tns_coder.c:18-39,258-277) */
         int f, sub, k = -1;
@@ -1237,13 +1244,13 @@ STAGE void st_tns(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__
 
 /* one bisection probe of R/estimate_global_gain.c:97-124 for this lane's candidate offset; the energies come from
  * lane registers (e0: j < 64, e1: j >= 64) through readlane, so the 100-step serial chain never touches LDS */
-__device__ __forceinline__ bool gain_probe(const lc3d_plan* __restrict__ P, float e0, float e1, int nq, int cand, float target)
+__device__ __forceinline__ bool gain_probe(float thr7, float thr50, float e0, float e1, int nq, int cand, float target)
 {
     float ener = 0; int iszero = 1;
-    const float fc = (float)cand, thr7 = P->c_thr7_up, thr50 = P->c_thr50_dn;
-#define GSTEP(ev) do { const float t = (ev) - fc; \
-        if (t < thr7) { if (iszero == 0) ener = (float)((double)ener + (2.7) * (28.0 / 20.0)); } \
-        else { if (t > thr50) ener = (float)((double)ener + 2.0 * (double)t - (50.0) * (28.0 / 20.0)); else ener = ener + t; iszero = 0; } } while (0)
+    const float fc = (float)cand;
+#define GSTEP(ev) do { const float t = (ev) - fc; const bool lo = t < thr7, hi = t > thr50; \
+        const float e_c = (float)((double)ener + (2.7) * (28.0 / 20.0)), e_b = (float)((double)ener + 2.0 * (double)t - (50.0) * (28.0 / 20.0)), e_a = ener + t; \
+        ener = lo ? (iszero ? ener : e_c) : (hi ? e_b : e_a); iszero = lo ? iszero : 0; } while (0)
     for (int j = nq - 1; j >= 64; j--) GSTEP(rl_f(e1, j - 64));
     for (int j = imin(nq, 64) - 1; j >= 0; j--) GSTEP(rl_f(e0, j));
 #undef GSTEP
@@ -1253,7 +1260,7 @@ __device__ __forceinline__ bool gain_probe(const lc3d_plan* __restrict__ P, floa
 /* ---- global gain estimate R/estimate_global_gain.c:30-137 ---- */
 STAGE void st_gain_estimate(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ C, WaveLds& L, int lane, int nbitsSQ)
 {
-    const int lg = P->ylen, off = C->gg_off, nq = lg >> 2;
+    const int lg = PI(ylen), off = CI(gg_off), nq = lg >> 2;
     float tbits_off = unif(L.fsc[F_TBITS_OFF]);
     int mem_target = uni(L.isc[I_MEM_TARGET]); const int mem_spec = uni(L.isc[I_MEM_SPEC]);
     if (mem_target < 0) tbits_off = 0;
@@ -1268,8 +1275,8 @@ STAGE void st_gain_estimate(const lc3d_plan* __restrict__ P, const lc3d_chan* __
     for (int i = lane; i < lg; i += WAVE) xm = fmaxf(xm, fabsf(L.A[i]));
     const float x_max = unif(wave_max_f(xm));
     float reg_val = 0;
-    if (P->hrmode && C->reg_bits > 0) {
-        float M0 = 1e-5f, M1 = 1e-5f; const float thresh = 2 * P->frame_ms;
+    if (PI(hrmode) && CI(reg_bits) > 0) {
+        float M0 = 1e-5f, M1 = 1e-5f; const float thresh = 2 * PF(frame_ms);
         for (int i0 = 0; i0 < lg; i0 += WAVE) {                      /* R/estimate_global_gain.c:58-62, serial in double */
             const int i = i0 + lane;
             const double ax = i < lg ? fabs((double)L.A[i]) : 0.0, ix = (double)i * ax;
@@ -1278,12 +1285,12 @@ STAGE void st_gain_estimate(const lc3d_plan* __restrict__ P, const lc3d_chan* __
         }
         const float q = M1 / M0;
         const float rB = 8 * (1 - (q < thresh ? q : thresh) / thresh);
-        reg_val = x_max * m_powf(2.0f, (float)(-C->reg_bits) - rB);
+        reg_val = x_max * m_powf(2.0f, (float)(-CI(reg_bits)) - rB);
     }
     float ind = 0, ind_min = 0;
     if (x_max == 0) { ind_min = (float)off; ind = 0; mem_target = -1; }
     else {
-        const float g_min = P->hrmode == 1 ? x_max / (float)(32768 * 256 - 2) : (float)((double)x_max / (32768 - 0.375));
+        const float g_min = PI(hrmode) == 1 ? x_max / (float)(32768 * 256 - 2) : (float)((double)x_max / (32768 - 0.375));
         ind_min = (float)ceil(28.0 * (double)m_log10f(g_min));
         float e[2] = {0, 0};
 #pragma unroll
@@ -1293,23 +1300,24 @@ STAGE void st_gain_estimate(const lc3d_plan* __restrict__ P, const lc3d_chan* __
                 const float* x = &L.A[4 * j];
                 float t = x[0] * x[0];
                 t += x[1] * x[1]; t += x[2] * x[2]; t += x[3] * x[3];
-                e[h] = (float)((28.0 / 20.0) * (7 + 10.0 * (double)m_log10f(t + reg_val + P->c_2m31)));
+                e[h] = (float)((28.0 / 20.0) * (7 + 10.0 * (double)m_log10f(t + reg_val + PF(c_2m31))));
             }
         }
         const float target = (float)((28.0 / 20.0) * (1.4) * (double)nbitsSQ);
+        const float thr7 = PF(c_thr7_up), thr50 = PF(c_thr50_dn);
         const int offset0 = 255 + off;
         /* 8-step bisection, evaluated speculatively: lanes 1..63 are the decision-tree nodes of the first six steps */
         int m = 0;
         {
             const int lvl = lane ? ilog2((unsigned)lane) : 0, p = lane - (1 << lvl);
             const int cand = offset0 - (p << (8 - lvl)) - (128 >> lvl);
-            const unsigned long long addback = __ballot(gain_probe(P, e[0], e[1], nq, cand, target));
+            const unsigned long long addback = __ballot(gain_probe(thr7, thr50, e[0], e[1], nq, cand, target));
             int node = 1;
             for (int i = 0; i < 6; i++) { const int nb = ((addback >> node) & 1ull) ? 0 : 1; m += nb << (7 - i); node = 2 * node + nb; }
         }
         {   /* last two steps: lane 0: step 6; lane 1: step 7 if step 6 added back; lane 2: step 7 otherwise */
             const int cand = lane == 0 ? offset0 - m - 2 : lane == 1 ? offset0 - m - 1 : offset0 - m - 3;
-            const unsigned long long addback = __ballot(gain_probe(P, e[0], e[1], nq, cand, target));
+            const unsigned long long addback = __ballot(gain_probe(thr7, thr50, e[0], e[1], nq, cand, target));
             if (addback & 1ull) { if (!(addback & 2ull)) m += 1; }
             else { m += 2; if (!(addback & 4ull)) m += 1; }
         }
@@ -1328,8 +1336,8 @@ STAGE void st_gain_estimate(const lc3d_plan* __restrict__ P, const lc3d_chan* __
 /* ---- quantisation + exact bit estimate R/quantize_spec.c:26-197 ---- */
 STAGE void st_quantize(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ C, WaveLds& L, int lane, int mode, int target)
 {
-    const int nt = P->ylen, fs = P->fs, tb = C->total_bits;
-    const float offs = P->hrmode ? 0.5f : 0.375f;
+    const int nt = PI(ylen), fs = PI(fs), tb = CI(total_bits);
+    const float offs = PI(hrmode) ? 0.5f : 0.375f;
     const float gain = unif(L.fsc[F_GAIN]);
     int* xq = XQ(L); uint32_t* cd = CD(L); uint32_t* cf = CF(L);
     for (int i = lane; i < nt; i += WAVE) {
@@ -1398,9 +1406,9 @@ STAGE void st_quantize(const lc3d_plan* __restrict__ P, const lc3d_chan* __restr
 }
 
 /* ---- R/adjust_global_gain.c:13-50 (wave-uniform scalars) ---- */
-__device__ __forceinline__ void gain_adjust(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ C, int& gg, int gg_min, float& gain, int target, int nBits, int& change)
+__device__ __forceinline__ void gain_adjust(const lc3d_plan* __restrict__ P, WaveLds& L, int& gg, int gg_min, float& gain, int target, int nBits, int& change)
 {
-    const int f = P->fs_idx, off = C->gg_off;
+    const int f = PI(fs_idx), off = CI(gg_off);
     float delta;
     if (nBits < lc3t_gg_p1[f]) delta = (float)(((double)nBits + 48.0) / 16.0);
     else if (nBits < lc3t_gg_p2[f]) delta = ((float)nBits + lc3t_gg_d[f]) * lc3t_gg_c[f];
@@ -1423,7 +1431,7 @@ __device__ __forceinline__ void gain_adjust(const lc3d_plan* __restrict__ P, con
 /* ---- noise factor R/noise_factor.c:13-108 ---- */
 STAGE void st_noise_factor(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ C, WaveLds& L, int lane, int bw_bin)
 {
-    const int width = P->dms == 100 ? 8 : 4, first = P->dms == 100 ? 24 : P->dms == 50 ? 12 : 6, hw = (width - 2) / 2;
+    const int width = PI(dms) == 100 ? 8 : 4, first = PI(dms) == 100 ? 24 : PI(dms) == 50 ? 12 : 6, hw = (width - 2) / 2;
     const float gg = unif(L.fsc[F_GAIN]);
     const int* xq = XQ(L);
     float* val = L.B; uint16_t* zk = ZKL(L);
@@ -1446,7 +1454,7 @@ STAGE void st_noise_factor(const lc3d_plan* __restrict__ P, const lc3d_chan* __r
     }
     LSYNC();
     float fac = 0;
-    const bool split = C->nbytes <= 20 && P->dms == 100 && nz > 0;
+    const bool split = CI(nbytes) <= 20 && PI(dms) == 100 && nz > 0;
     const int msplit = split ? sumz / nz : 0x7fffffff;
     float m1 = 0, m2 = 0; int j1 = 0;
     for (int i0 = 0; i0 < nz; i0 += WAVE) {         /* serial float sums in index order, operands through readlane */
@@ -1474,16 +1482,16 @@ STAGE void st_residual(const lc3d_plan* __restrict__ P, WaveLds& L, int lane, in
     const float gain = unif(L.fsc[F_GAIN]);
     uint8_t* res = RESB(L);
     int nnz = 0;
-    for (int k0 = 0; k0 < P->ylen; k0 += WAVE) {
+    for (int k0 = 0; k0 < PI(ylen); k0 += WAVE) {
         const int k = k0 + lane;
-        const bool nzq = k < P->ylen && xq[k] != 0;
+        const bool nzq = k < PI(ylen) && xq[k] != 0;
         const unsigned long long mk = __ballot(nzq);
         if (nzq) nzi[nnz + __popcll(mk & ((1ull << lane) - 1ull))] = (uint16_t)k;
         nnz += __popcll(mk);
     }
     int m = targetBits - nBits + 4;
-    if (P->hrmode) m += 10;
-    const int iter_max = P->hrmode ? 20 : 1;
+    if (PI(hrmode)) m += 10;
+    const int iter_max = PI(hrmode) ? 20 : 1;
     for (int i = lane; i < 160; i += WAVE) ((uint32_t*)res)[i] = 0;
     LSYNC();
     int n = 0, iter = 0; float offset = .25f;
@@ -1587,7 +1595,7 @@ STAGE void st_bitstream(const lc3d_plan* __restrict__ P, const lc3d_chan* __rest
 {
     int* isc = L.isc;
     uint8_t* bytes = L.bytes;
-    const int nbytes = C->nbytes;
+    const int nbytes = CI(nbytes);
     const int nfilt = uni(isc[I_TNS_NF]);
     const int lastnz = uni(isc[I_LASTNZ]), lsbMode = uni(isc[I_LSB]), nres = uni(isc[I_NRES]);
     const int bw_idx = uni(isc[I_BW]), gg = uni(isc[I_GG]), fac_ns = uni(isc[I_FACNS]);
@@ -1598,8 +1606,8 @@ STAGE void st_bitstream(const lc3d_plan* __restrict__ P, const lc3d_chan* __rest
         if (Q < 64) { slo |= v_ << Q; if (Q + (n_) > 64) shi |= v_ >> (64 - Q); } else shi |= v_ << (Q - 64); Q += (n_); } while (0)
     {
         const int gain_msb_bits[4] = {1, 1, 2, 2}, gain_lsb_bits[4] = {0, 1, 0, 1};
-        if (P->bw_bits > 0) SIDE(bw_idx, P->bw_bits);
-        SIDE(lastnz / 2 - 1, ilog2((unsigned)(P->ylen / 2 - 1)) + 1);
+        if (PI(bw_bits) > 0) SIDE(bw_idx, PI(bw_bits));
+        SIDE(lastnz / 2 - 1, ilog2((unsigned)(PI(ylen) / 2 - 1)) + 1);
         SIDE(lsbMode, 1);
         SIDE(gg, 8);
         for (int i = 0; i < nfilt; i++) SIDE(imin(1, isc[I_TNS_ORD0 + i]), 1);
@@ -1636,7 +1644,7 @@ STAGE void st_bitstream(const lc3d_plan* __restrict__ P, const lc3d_chan* __rest
     for (int i = 0; i < nfilt; i++) {
         const int ord = uni(isc[I_TNS_ORD0 + i]);
         if (ord > 0) {
-            const uint16_t* oc = &lc3t_tns_order_cum[C->lpc_weighting * 9];
+            const uint16_t* oc = &lc3t_tns_order_cum[CI(lpc_weighting) * 9];
             ari_encode(w, bytes, lane, uni(oc[ord] - oc[ord - 1]), uni(oc[ord - 1]));
             for (int j = 0; j < ord; j++) {
                 const uint16_t* cc = &lc3t_tns_coef_cum[j * 18]; const int id = uni(isc[I_TNS_IDX0 + i * 8 + j]);
@@ -1702,7 +1710,7 @@ STAGE void st_bitstream(const lc3d_plan* __restrict__ P, const lc3d_chan* __rest
         }
     }
     /* ---- residual / LSB bits (R/ari_codec.c:764-797) ---- */
-    const int total = C->total_bits;
+    const int total = CI(total_bits);
     const int bp_side = nbytes - 1 - (Q >> 3), mask_log = Q & 7;
     const int nbits_side = total - (8 * (bp_side + 1) + 8 - mask_log);
     int nbits_ari = (w.bp + 1) * 8 + 25 - flog2f_int((unsigned)w.range);
@@ -1758,8 +1766,11 @@ lc3_encode_kernel(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__
     const int lane = threadIdx.x;
     const int cs = blockIdx.x;
     if (cs >= ncs) return;
+    if (lane < 48) L.pc[lane] = ((const int*)P)[lane];
+    if (lane < 16) L.cc[lane] = ((const int*)&chans[cs])[lane];
+    LSYNC();
     const lc3d_chan* __restrict__ C = &chans[cs];
-    const int N = P->N, channels = P->channels, ml = N - P->la;
+    const int N = PI(N), channels = PI(channels), ml = N - PI(la);
     const int strm = cs / channels, ch = cs - strm * channels;
 
     /* ---- load cross-frame state ---- */
@@ -1770,7 +1781,7 @@ lc3_encode_kernel(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__
     if (lane < 16) L.fsc[lane] = stp[LC3D_ST_SCAL + lane];
     if (lane < 16) L.isc[lane] = ((const int*)stp)[LC3D_ST_SCAL + 16 + lane];
     LSYNC();
-    if (C->reset_attack && lane == 0) { L.fsc[F_ATT_M0] = 0; L.fsc[F_ATT_M1] = 0; L.fsc[F_ATT_ACC] = 0; L.isc[I_ATT_POS] = 0; L.isc[I_ATT_FLAG] = 0; }
+    if (CI(reset_attack) && lane == 0) { L.fsc[F_ATT_M0] = 0; L.fsc[F_ATT_M1] = 0; L.fsc[F_ATT_ACC] = 0; L.isc[I_ATT_POS] = 0; L.isc[I_ATT_FLAG] = 0; }
     LSYNC();
 #ifdef LC3_STAGE_TIMING
     if (lane < NSTAGE) L.tacc[lane] = 0;
@@ -1800,12 +1811,12 @@ lc3_encode_kernel(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__
 
         st_resample(P, L, lane);
         TICK(2);
-        if (tr) for (int i = lane; i < P->len12 + 1; i += WAVE) tr->s12k8[i] = L.h12[384 - P->len12 - 24 + i];
+        if (tr) for (int i = lane; i < PI(len12) + 1; i += WAVE) tr->s12k8[i] = L.h12[384 - PI(len12) - 24 + i];
         st_olpa(P, L, lane);
         TICK(3);
         st_ltpf(P, C, L, lane);
         TICK(4);
-        if (C->attack_handling) st_attack(P, L, lane);
+        if (CI(attack_handling)) st_attack(P, L, lane);
         TICK(5);
         st_mdct(P, L, lane);
         TICK(1);
@@ -1814,7 +1825,7 @@ lc3_encode_kernel(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__
         TICK(6);
         if (tr) { if (lane == 0) { tr->T0 = L.isc[I_T0]; tr->normcorr = L.fsc[F_NC]; tr->ltpf_param[0] = L.isc[I_LTPF0]; tr->ltpf_param[1] = L.isc[I_LTPF1];
                                    tr->ltpf_param[2] = L.isc[I_LTPF2]; tr->ltpf_bits = L.isc[I_LTPF_BITS]; tr->attack = L.isc[I_ATT_FLAG]; }
-                  tr->ener[lane] = lane < P->nbands ? L.sm[SM_ENER + lane] : 0; }
+                  tr->ener[lane] = lane < PI(nbands) ? L.sm[SM_ENER + lane] : 0; }
         LSYNC();
         st_sns_scf(P, L, lane);
         TICK(7);
@@ -1826,16 +1837,16 @@ lc3_encode_kernel(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__
         if (tr) { if (lane < 16) tr->scf_q[lane] = L.sm[SM_SCFQ + lane]; if (lane < 7) tr->scf_idx[lane] = L.isc[I_SCF0 + lane];
                   for (int i = lane; i < N; i += WAVE) tr->spec_shaped[i] = L.A[i]; }
         int bw = uni(L.isc[I_BW]);
-        if (C->bandwidth) {                                  /* R/cutoff_bandwidth.c:13-26 */
-            const int bin = C->bw_cut_bin;
-            if (P->ylen > bin) {
+        if (CI(bandwidth)) {                                  /* R/cutoff_bandwidth.c:13-26 */
+            const int bin = CI(bw_cut_bin);
+            if (PI(ylen) > bin) {
                 if (lane < 4) { const float sc4[4] = {0.5f, 0.25f, 0.125f, 0.0625f}; L.A[bin - 1 + lane] = L.A[bin - 1 + lane] * sc4[lane]; }
-                for (int i = bin + 3 + lane; i < P->ylen; i += WAVE) L.A[i] = 0;
+                for (int i = bin + 3 + lane; i < PI(ylen); i += WAVE) L.A[i] = 0;
             }
-            bw = imin(bw, C->bw_index);
+            bw = imin(bw, CI(bw_index));
             if (lane == 0) L.isc[I_BW] = bw;
         }
-        const int bw_bin = lc3t_bw_bins[P->bw_cls * 6 + bw];
+        const int bw_bin = lc3t_bw_bins[PI(bw_cls) * 6 + bw];
         if (lane < 16) L.isc[I_TNS_IDX0 + lane] = 0;
         if (lane < 2) L.isc[I_TNS_ORD0 + lane] = 0;
         LSYNC();
@@ -1845,7 +1856,7 @@ lc3_encode_kernel(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__
         if (tr) { if (lane == 0) { tr->bw_idx = bw; tr->tns_nfilt = L.isc[I_TNS_NF]; tr->tns_order[0] = L.isc[I_TNS_ORD0]; tr->tns_order[1] = L.isc[I_TNS_ORD1]; tr->tns_bits = tns_bits; }
                   if (lane < 16) tr->tns_rc_idx[lane] = L.isc[I_TNS_IDX0 + lane];
                   for (int i = lane; i < N; i += WAVE) tr->spec_tns[i] = L.A[i]; }
-        const int tbq = C->target_bits_init - (tns_bits + uni(L.isc[I_LTPF_BITS]));
+        const int tbq = CI(target_bits_init) - (tns_bits + uni(L.isc[I_LTPF_BITS]));
         st_gain_estimate(P, C, L, lane, tbq);
         TICK(11);
         if (tr && lane == 0) { tr->target_bits_quant = tbq; tr->gain0 = L.fsc[F_GAIN]; tr->gg_idx0 = L.isc[I_GG]; tr->gg_min = L.isc[I_GGMIN]; }
@@ -1855,7 +1866,7 @@ lc3_encode_kernel(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__
             int gg = uni(L.isc[I_GG]), change; float gain = unif(L.fsc[F_GAIN]);
             const int nbits0 = uni(L.isc[I_NBITS]);
             if (tr && lane == 0) tr->nbits0 = nbits0;
-            gain_adjust(P, C, gg, uni(L.isc[I_GGMIN]), gain, tbq, nbits0, change);
+            gain_adjust(P, L, gg, uni(L.isc[I_GGMIN]), gain, tbq, nbits0, change);
             LSYNC();
             if (lane == 0) { L.isc[I_MEM_SPEC] = nbits0; L.isc[I_GG] = gg; L.fsc[F_GAIN] = gain; L.isc[I_CHANGE] = change; }
             LSYNC();
@@ -1866,7 +1877,7 @@ lc3_encode_kernel(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__
         TICK(14);
         if (tr) { if (lane == 0) { tr->gain = L.fsc[F_GAIN]; tr->gg_idx = L.isc[I_GG]; tr->gain_change = L.isc[I_CHANGE]; tr->nbits = L.isc[I_NBITS]; tr->nbits2 = L.isc[I_NBITS2];
                                    tr->lastnz = L.isc[I_LASTNZ]; tr->lsb_mode = L.isc[I_LSB]; tr->fac_ns = L.isc[I_FACNS]; }
-                  for (int i = lane; i < N; i += WAVE) tr->xq[i] = i < P->ylen ? XQ(L)[i] : 0; }
+                  for (int i = lane; i < N; i += WAVE) tr->xq[i] = i < PI(ylen) ? XQ(L)[i] : 0; }
         if (uni(L.isc[I_LSB]) == 0) st_residual(P, L, lane, tbq, uni(L.isc[I_NBITS2]));
         else { for (int i = lane; i < 160; i += WAVE) ((uint32_t*)RESB(L))[i] = 0; if (lane == 0) L.isc[I_NRES] = 0; LSYNC(); }
         TICK(15);
@@ -1875,8 +1886,8 @@ lc3_encode_kernel(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__
         TICK(16);
         if (tr && lane == 0) { tr->n_res_bits = L.isc[I_NRES]; tr->bp_side = L.isc[I_BP_SIDE]; tr->mask_side = L.isc[I_MASK_SIDE]; }
         /* ---- bytes out ---- */
-        uint8_t* o = out + ((size_t)strm * T + t) * out_stride + C->out_off;
-        for (int i = lane; i < C->nbytes; i += WAVE) o[i] = L.bytes[i];
+        uint8_t* o = out + ((size_t)strm * T + t) * out_stride + CI(out_off);
+        for (int i = lane; i < CI(nbytes); i += WAVE) o[i] = L.bytes[i];
         LSYNC();
         TICK(17);
     }
