@@ -48,19 +48,17 @@
 /* LDS slice of one wave (~12.8 KB -> 12 waves per CU)                                                */
 /* ------------------------------------------------------------------------------------------------ */
 struct __attribute__((aligned(16))) WaveLds {
-    float xbuf[MEMCAP + MAXN];  /* [MDCT/resampler memory right-aligned in 0..MEMCAP | current frame]; after the time-domain
-                                   stages and the MDCT the frame half is reused for the quantised spectrum (xq) */
-    float A[MAXN];              /* scratch, then the MDCT spectrum (shaped / TNS-filtered in place) */
-    float B[MAXN];              /* scratch */
+    float xbuf[MEMCAP + MAXN];  /* [MDCT/resampler memory right-aligned in 0..MEMCAP | current frame X]; once the MDCT fold has consumed the
+                                   frame, X is scratch (DFT ping buffer, TNS output) and finally the quantised spectrum xq */
+    float A[MAXN];              /* scratch, then the MDCT spectrum (shaped / TNS-filtered in place); the output frame during the bitstream stage */
     float h12[384];             /* HP-filtered 12.8 kHz stream, newest sample at [383] */
-    float h6[196];              /* 6.4 kHz stream, newest at [193] */
-    float sm[704];              /* small vectors (SM_*); from quantisation on: cd[240] | cf[240] | zero-line list / residual bits */
-    int   pc[48];               /* the scalar head of the plan (lc3d_plan up to pad0), copied once: stage code reads it from LDS
+    float h6[194];              /* 6.4 kHz stream, newest at [193] */
+    float sm[548];              /* small vectors (SM_*); from quantisation on: cdw[240] | residual / LSB bits (160 words) */
+    int   pc[42];               /* the scalar head of the plan (lc3d_plan up to pad0), copied once: stage code reads it from LDS
                                    instead of through a flat pointer, and readfirstlane makes the values scalar */
-    int   cc[16];               /* this channel-stream's lc3d_chan */
-    float fsc[16];              /* float scalars: cross-frame state + values passed between stages */
-    int   isc[80];              /* integer scalars */
-    uint8_t bytes[416];         /* the output frame */
+    int   cc[14];               /* this channel-stream's lc3d_chan */
+    float fsc[12];              /* float scalars: cross-frame state + values passed between stages */
+    int   isc[56];              /* integer scalars */
 #ifdef LC3_STAGE_TIMING
     long long tacc[NSTAGE];
 #endif
@@ -71,22 +69,21 @@ struct __attribute__((aligned(16))) WaveLds {
 #define XCUR(L) (&(L).xbuf[MEMCAP])
 #define XQ(L)   ((int*)&(L).xbuf[MEMCAP])
 #define SPEC(L) ((L).A)
-#define CD(L)   ((uint32_t*)&(L).sm[0])      /* per 2-tuple: ctx | (maxlev+1)<<10 | sym<<16 */
-#define CF(L)   ((uint32_t*)&(L).sm[240])    /* per 2-tuple: cumfreq | symfreq<<16 of the final symbol */
-#define RESB(L) ((uint8_t*)&(L).sm[480])     /* 640 bytes: residual bits / LSB-mode list (bit-packed, LSB first) */
-#define ZKL(L)  ((uint16_t*)&(L).sm[480])    /* noise factor: 1-based indices of the zero lines */
+#define BYTES(L) ((uint8_t*)(L).A)            /* 416 bytes, valid from the bitstream stage to the copy-out */
+#define CDW(L)  ((uint32_t*)&(L).sm[0])      /* per 2-tuple: ctx(10) | maxlev+1 (6) | pki of the final symbol (6) | sym (5) */
+#define RESB(L) ((uint8_t*)&(L).sm[240])     /* 640 bytes: residual bits / LSB-mode list (bit-packed, LSB first) */
 
 /* sm[] map (floats) before quantisation */
-#define SM_ENER   0     /* 64  band energies (modified in place by SNS) */
-#define SM_GI     64    /* 64  interpolated SNS gains */
-#define SM_SCF    128   /* 16 */
-#define SM_SCFQ   144   /* 16 */
-#define SM_TGT    160   /* 16 pvq target (dct domain) */
-#define SM_TGTP   176   /* 16 pvq target pre */
-#define SM_ST1    192   /* 16 */
-#define SM_VEC    208   /* 6*16 = 96: candidate vectors */
-#define SM_PVQ    304   /* 4 searches x (y[16] int, ynorm[16]) = 128 */
-#define SM_MISC   512   /* 192: R0 (98), cor, tns r[], idct in/out ... */
+#define SM_ENER   0     /* 64  band energies, later the interpolated SNS gains */
+#define SM_GI     0
+#define SM_SCF    64    /* 16 */
+#define SM_SCFQ   80    /* 16 */
+#define SM_TGT    96    /* 16 pvq target (dct domain) */
+#define SM_TGTP   112   /* 16 pvq target pre */
+#define SM_ST1    128   /* 16 */
+#define SM_VEC    144   /* 6*16 = 96: candidate vectors */
+#define SM_PVQ    240   /* 4 searches x (y[16] int, ynorm[16]) = 128 */
+#define SM_MISC   368   /* 180: R0 (98), cor, tns r[], idct in/out ... */
 
 /* fsc[] map */
 enum { F_HP0 = 0, F_HP1, F_LTPF_NC1, F_LTPF_NC2, F_LTPF_PITCH, F_ATT_M0, F_ATT_M1, F_ATT_ACC, F_TBITS_OFF, F_NC, F_GAIN };
@@ -541,7 +538,7 @@ STAGE void st_attack(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
     if (lane == 0) { p[-2] = L.fsc[F_ATT_M0]; p[-1] = L.fsc[F_ATT_M1]; }
     LSYNC();
     const float nm0 = p[n16 - 2], nm1 = p[n16 - 1];
-    float* fs = L.B;
+    float* fs = &L.A[200];
     for (int i = lane; i < 160; i += WAVE) {
         float t = 0;
         t = (float)((double)t + (double)p[i] * 0.375);
@@ -570,96 +567,169 @@ STAGE void st_attack(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
 /* ------------------------------------------------------------------------------------------------ */
 /* MDCT: R/mdct.c:103-124 + R/dct4.c:75-95 + R/fft/fft_240_480.h:16-88 / R/fft/fft_generic.h:634-699  */
 /* ------------------------------------------------------------------------------------------------ */
-STAGE void mdct_dft240_cols(WaveLds& L, int lane)   /* 15 transforms of length 16, in place in A */
+/* One half of the 16-point kernel (R/fft/fft_15_16.h:214-401): ODD = false produces the 8 even-indexed outputs from the sums
+ * E[i] = v[i] + v[i+16], ODD = true the 8 odd-indexed outputs from the differences O[i].  Operation for operation identical to
+ * dft16(); splitting it lets two lanes share one transform (half the registers, half the latency). */
+template <bool ODD> __device__ __forceinline__ void dft16_half(const float* v, float* o /* 8 complex outputs: k = ODD + 2j */)
 {
-    if (lane < 15) {
+    const float S = 7.071067811865475e-1f, C1 = 9.238795325112867e-1f, C3 = 3.826834323650898e-1f;
+    const float SP = 2.414213562373095f, SM = 4.142135623730952e-1f;
+    if (!ODD) {
+        float E[16], P[16], Q[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) E[i] = v[i] + v[i + 16];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            P[4 * k + 0] = E[2 * k] + E[2 * k + 8];     P[4 * k + 2] = E[2 * k] - E[2 * k + 8];
+            P[4 * k + 1] = E[2 * k + 1] + E[2 * k + 9]; P[4 * k + 3] = E[2 * k + 1] - E[2 * k + 9];
+        }
+        Q[0] = P[0] + P[8];   Q[4] = P[0] - P[8];   Q[1] = P[1] + P[9];   Q[5] = P[1] - P[9];
+        Q[8] = P[2] - P[11];  Q[10] = P[2] + P[11]; Q[9] = P[3] + P[10];  Q[11] = P[3] - P[10];
+        Q[2] = P[4] + P[12];  Q[7] = P[4] - P[12];  Q[3] = P[5] + P[13];  Q[6] = P[13] - P[5];
+        const float a1 = P[6] + P[14], a2 = P[6] - P[14], a0 = P[7] + P[15], a3 = P[7] - P[15];
+        Q[12] = (a0 + a2) * S; Q[14] = (a0 - a2) * S; Q[13] = (a3 - a1) * S; Q[15] = (a1 + a3) * -S;
+        o[0] = Q[0] + Q[2];    o[1] = Q[1] + Q[3];      /* k = 0  */
+        o[2] = Q[10] + Q[12];  o[3] = Q[11] + Q[13];    /* k = 2  */
+        o[4] = Q[4] - Q[6];    o[5] = Q[5] - Q[7];      /* k = 4  */
+        o[6] = Q[8] + Q[14];   o[7] = Q[9] + Q[15];     /* k = 6  */
+        o[8] = Q[0] - Q[2];    o[9] = Q[1] - Q[3];      /* k = 8  */
+        o[10] = Q[10] - Q[12]; o[11] = Q[11] - Q[13];   /* k = 10 */
+        o[12] = Q[4] + Q[6];   o[13] = Q[5] + Q[7];     /* k = 12 */
+        o[14] = Q[8] - Q[14];  o[15] = Q[9] - Q[15];    /* k = 14 */
+    } else {
+        float O[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) O[i] = v[i] - v[i + 16];
+        float g9 = (O[2] + O[14]) * -C3, g10 = (O[2] - O[14]) * C1, g8 = (O[3] + O[15]) * C3, g11 = (O[3] - O[15]) * C1;
+        const float g5 = (O[4] + O[12]) * -S,  g6 = (O[4] - O[12]) * S,   g4 = (O[5] + O[13]) * S,  g7 = (O[5] - O[13]) * S;
+        const float g13 = (O[6] + O[10]) * -C1, g14 = (O[6] - O[10]) * C3, g12 = (O[7] + O[11]) * C1, g15 = (O[7] - O[11]) * C3;
+        const float u2 = g8 * SP - g12 * SM, u3 = g9 * SP - g13 * SM, u4 = g10 * SM - g14 * SP, u5 = g11 * SM - g15 * SP;
+        g8 += g12; g9 += g13; g10 += g14; g11 += g15;
+        const float w6 = O[0] + g4, w10 = O[0] - g4, w7 = O[1] + g5, w11 = O[1] - g5;
+        const float w12 = g6 - O[9], w14 = g6 + O[9], w13 = O[8] + g7, w15 = O[8] - g7;
+        const float r10 = w6 - w14, r12 = w6 + w14, r11 = w7 + w15, r13 = w7 - w15;
+        const float r14 = w10 + w12, r16 = w10 - w12, r15 = w11 + w13, r17 = w11 - w13;
+        const float h10 = g8 + g10, d10 = g8 - g10, h11 = g9 + g11, d11 = g9 - g11;
+        const float s12 = u2 + u4, d12 = u2 - u4, s13 = u3 + u5, d13 = u3 - u5;
+        o[0] = r12 + h10;  o[1] = r13 + h11;    /* k = 1  */
+        o[2] = r10 + s12;  o[3] = r11 + s13;    /* k = 3  */
+        o[4] = r16 + d12;  o[5] = r17 + d13;    /* k = 5  */
+        o[6] = r14 + d10;  o[7] = r15 + d11;    /* k = 7  */
+        o[8] = r12 - h10;  o[9] = r13 - h11;    /* k = 9  */
+        o[10] = r10 - s12; o[11] = r11 - s13;   /* k = 11 */
+        o[12] = r16 - d12; o[13] = r17 - d13;   /* k = 13 */
+        o[14] = r14 - d10; o[15] = r15 - d11;   /* k = 15 */
+    }
+}
+
+STAGE void mdct_dft240_cols(WaveLds& L, int lane)   /* 15 transforms of length 16, in place in X; two lanes per transform */
+{
+    float* X = XCUR(L);
+    const int col = lane >> 1, odd = lane & 1;
+    float o[16];
+    if (lane < 30) {
         float v[32];
 #pragma unroll
-        for (int l = 0; l < 16; l++) { const int s = (225 * l + 16 * lane) % 240; v[2 * l] = L.A[2 * s]; v[2 * l + 1] = L.A[2 * s + 1]; }
-        dft16(v);
+        for (int l = 0; l < 16; l++) { const int s = (225 * l + 16 * col) % 240; v[2 * l] = X[2 * s]; v[2 * l + 1] = X[2 * s + 1]; }
+        if (odd) dft16_half<true>(v, o); else dft16_half<false>(v, o);
+    }
+    LSYNC();
+    if (lane < 30) {
 #pragma unroll
-        for (int l = 0; l < 16; l++) { const int s = (225 * l + 16 * lane) % 240; L.A[2 * s] = v[2 * l]; L.A[2 * s + 1] = v[2 * l + 1]; }
+        for (int j = 0; j < 8; j++) { const int l = odd + 2 * j, s = (225 * l + 16 * col) % 240; X[2 * s] = o[2 * j]; X[2 * s + 1] = o[2 * j + 1]; }
     }
     LSYNC();
 }
-STAGE void mdct_dft240_rows(WaveLds& L, int lane)   /* 16 transforms of length 15, A -> B in natural order */
+STAGE void mdct_dft240_rows(WaveLds& L, int lane)   /* 16 transforms of length 15, X -> A in natural order */
 {
+    const float* X = XCUR(L);
     if (lane < 16) {
         float v[30];
 #pragma unroll
-        for (int l = 0; l < 15; l++) { const int s = (225 * lane + 16 * l) % 240; v[2 * l] = L.A[2 * s]; v[2 * l + 1] = L.A[2 * s + 1]; }
+        for (int l = 0; l < 15; l++) { const int s = (225 * lane + 16 * l) % 240; v[2 * l] = X[2 * s]; v[2 * l + 1] = X[2 * s + 1]; }
         dft15(v);
 #pragma unroll
-        for (int l = 0; l < 15; l++) { const int d = (15 * lane + 16 * l) % 240; L.B[2 * d] = v[2 * l]; L.B[2 * d + 1] = v[2 * l + 1]; }
+        for (int l = 0; l < 15; l++) { const int d = (15 * lane + 16 * l) % 240; L.A[2 * d] = v[2 * l]; L.A[2 * d + 1] = v[2 * l + 1]; }
     }
     LSYNC();
 }
-STAGE void mdct_dft120(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)   /* 8 x 3 x 5 prime-factor DFT, A -> B */
+STAGE void mdct_dft120(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)   /* 8 x 3 x 5 prime-factor DFT, X -> A */
 {
+    float* X = XCUR(L);
     const uint8_t* m1 = P->pfa_src; const uint8_t* m2 = P->pfa_src + 120; const uint8_t* m3 = P->pfa_src + 240;
     if (lane < 15) {
         float v[16];
 #pragma unroll
-        for (int j = 0; j < 8; j++) { const int s = m1[lane * 8 + j]; v[2 * j] = L.A[2 * s]; v[2 * j + 1] = L.A[2 * s + 1]; }
+        for (int j = 0; j < 8; j++) { const int s = m1[lane * 8 + j]; v[2 * j] = X[2 * s]; v[2 * j + 1] = X[2 * s + 1]; }
         dft8(v);
 #pragma unroll
-        for (int j = 0; j < 8; j++) { const int d = lane * 8 + j; L.B[2 * d] = v[2 * j]; L.B[2 * d + 1] = v[2 * j + 1]; }
+        for (int j = 0; j < 8; j++) { const int d = lane * 8 + j; L.A[2 * d] = v[2 * j]; L.A[2 * d + 1] = v[2 * j + 1]; }
     }
     LSYNC();
     if (lane < 40) {
         float v[6];
 #pragma unroll
-        for (int j = 0; j < 3; j++) { const int s = m2[lane * 3 + j]; v[2 * j] = L.B[2 * s]; v[2 * j + 1] = L.B[2 * s + 1]; }
+        for (int j = 0; j < 3; j++) { const int s = m2[lane * 3 + j]; v[2 * j] = L.A[2 * s]; v[2 * j + 1] = L.A[2 * s + 1]; }
         dft3(v);
 #pragma unroll
-        for (int j = 0; j < 3; j++) { const int d = lane * 3 + j; L.A[2 * d] = v[2 * j]; L.A[2 * d + 1] = v[2 * j + 1]; }
+        for (int j = 0; j < 3; j++) { const int d = lane * 3 + j; X[2 * d] = v[2 * j]; X[2 * d + 1] = v[2 * j + 1]; }
     }
     LSYNC();
     if (lane < 24) {
         float v[10];
 #pragma unroll
-        for (int j = 0; j < 5; j++) { const int s = m3[lane * 5 + j]; v[2 * j] = L.A[2 * s]; v[2 * j + 1] = L.A[2 * s + 1]; }
+        for (int j = 0; j < 5; j++) { const int s = m3[lane * 5 + j]; v[2 * j] = X[2 * s]; v[2 * j + 1] = X[2 * s + 1]; }
         dft5(v);
 #pragma unroll
-        for (int j = 0; j < 5; j++) { const int d = P->pfa_dst[lane * 5 + j]; L.B[2 * d] = v[2 * j]; L.B[2 * d + 1] = v[2 * j + 1]; }
+        for (int j = 0; j < 5; j++) { const int d = P->pfa_dst[lane * 5 + j]; L.A[2 * d] = v[2 * j]; L.A[2 * d + 1] = v[2 * j + 1]; }
     }
     LSYNC();
 }
 STAGE void st_mdct(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
 {
-    const int N = PI(N), h = N >> 1, la = PI(la);
+    const int N = PI(N), h = N >> 1, la = PI(la), ml = N - la;
     const float* w = &lc3t_win_pool[PI(win_off)];
-    const float* t = &L.xbuf[MEMCAP - (N - la)];    /* t[j] = [memory | frame], j < 2N-la ; zero beyond */
+    const float* t = &L.xbuf[MEMCAP - ml];          /* t[j] = [memory | frame], j < 2N-la ; zero beyond */
+    float* X = XCUR(L);
     const int lim = 2 * N - la;
-    for (int i = lane; i < h; i += WAVE) {
+    for (int i = lane; i < h; i += WAVE) {          /* window + fold (R/mdct.c:113-119) -> A */
         const int j0 = 3 * h - i - 1, j1 = 3 * h + i, j2 = i, j3 = 2 * h - i - 1;
         const float a0 = (j0 < lim ? t[j0] : 0.0f) * w[j0];
         const float a1 = (j1 < lim ? t[j1] : 0.0f) * w[j1];
         const float a2 = t[j2] * w[j2];
         const float a3 = t[j3] * w[j3];
-        L.B[i] = -a0 - a1;
-        L.B[h + i] = a2 - a3;
+        L.A[i] = -a0 - a1;
+        L.A[h + i] = a2 - a3;
     }
     LSYNC();
-    for (int i = lane; i < h; i += WAVE) {          /* pre-twiddle R/dct4.c:84-86 */
-        const float ar = L.B[2 * i], ai = L.B[N - 2 * i - 1], br = P->tw1[2 * i], bi = P->tw1[2 * i + 1];
-        L.A[2 * i] = ar * br - ai * bi;
-        L.A[2 * i + 1] = ai * br + ar * bi;
+    /* the frame's tail becomes the next frame's MDCT / resampler memory; the frame half of xbuf (X) is scratch from here on */
+    for (int i = lane; i < ml; i += WAVE) L.xbuf[MEMCAP - ml + i] = L.xbuf[MEMCAP + N - ml + i];
+    LSYNC();
+    for (int i = lane; i < h; i += WAVE) {          /* pre-twiddle R/dct4.c:84-86: A -> X */
+        const float ar = L.A[2 * i], ai = L.A[N - 2 * i - 1], br = P->tw1[2 * i], bi = P->tw1[2 * i + 1];
+        X[2 * i] = ar * br - ai * bi;
+        X[2 * i + 1] = ai * br + ar * bi;
     }
     LSYNC();
     if (h == 240) { mdct_dft240_cols(L, lane); mdct_dft240_rows(L, lane); }
     else mdct_dft120(P, L, lane);
     const float norm = PF(dct4_norm);
-    for (int i = lane; i < h; i += WAVE) {          /* post-twiddle R/dct4.c:90-94; the spectrum lands in A */
-        const float ar = L.B[2 * i], ai = L.B[2 * i + 1], br = P->tw2[2 * i], bi = P->tw2[2 * i + 1];
-        const float tr = ar * br - ai * bi, ti = ai * br + ar * bi;
-        L.A[2 * i] = tr * norm;
-        L.A[N - 2 * i - 1] = -ti * norm;
+    float o0[4], o1[4];                              /* post-twiddle R/dct4.c:90-94, in place in A through registers (h <= 256) */
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int i = lane + 64 * k;
+        if (i < h) {
+            const float ar = L.A[2 * i], ai = L.A[2 * i + 1], br = P->tw2[2 * i], bi = P->tw2[2 * i + 1];
+            const float tr = ar * br - ai * bi, ti = ai * br + ar * bi;
+            o0[k] = tr * norm; o1[k] = -ti * norm;
+        }
     }
     LSYNC();
-    /* the frame's tail becomes the next frame's MDCT / resampler memory; the frame half of xbuf is free afterwards */
-    const int ml = N - la;
-    for (int i = lane; i < ml; i += WAVE) L.xbuf[MEMCAP - ml + i] = L.xbuf[MEMCAP + N - ml + i];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int i = lane + 64 * k;
+        if (i < h) { L.A[2 * i] = o0[k]; L.A[N - 2 * i - 1] = o1[k]; }
+    }
     LSYNC();
 }
 
@@ -1155,6 +1225,7 @@ STAGE void tns_lattice(WaveLds& L, int lane, int b_first, int cnt, int ord)
 {
     float* stt = &L.sm[SM_MISC + 96];
     const float* rcs = &L.sm[SM_MISC + 104];
+    float* X = XCUR(L);
     float rc[8], st[8], carried[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) { rc[j] = unif(rcs[j]); carried[j] = unif(stt[j]); st[j] = carried[j]; }
@@ -1174,7 +1245,7 @@ STAGE void tns_lattice(WaveLds& L, int lane, int b_first, int cnt, int ord)
         }
 #pragma unroll
         for (int j = 0; j < 8; j++) if (j == ord - 1) { s += rc[j] * st[j]; st[j] = save; }
-        if (t >= b0) L.B[t] = s;
+        if (t >= b0) X[t] = s;
     }
     const int lastLane = (cnt - 1) / chunk;
     LSYNC();
@@ -1182,7 +1253,7 @@ STAGE void tns_lattice(WaveLds& L, int lane, int b_first, int cnt, int ord)
 #pragma unroll
         for (int j = 0; j < 8; j++) stt[j] = st[j];
     }
-    for (int t = b_first + lane; t < b_first + cnt; t += WAVE) L.A[t] = L.B[t];
+    for (int t = b_first + lane; t < b_first + cnt; t += WAVE) L.A[t] = X[t];
     LSYNC();
 }
 
@@ -1339,7 +1410,7 @@ STAGE void st_quantize(const lc3d_plan* __restrict__ P, const lc3d_chan* __restr
     const int nt = PI(ylen), fs = PI(fs), tb = CI(total_bits);
     const float offs = PI(hrmode) ? 0.5f : 0.375f;
     const float gain = unif(L.fsc[F_GAIN]);
-    int* xq = XQ(L); uint32_t* cd = CD(L); uint32_t* cf = CF(L);
+    int* xq = XQ(L); uint32_t* cdw = CDW(L);
     for (int i = lane; i < nt; i += WAVE) {
         const float x = L.A[i];
         const int sg = x > 0 ? 1 : x < 0 ? -1 : 0;
@@ -1384,10 +1455,8 @@ STAGE void st_quantize(const lc3d_plan* __restrict__ P, const lc3d_chan* __restr
                 if (lev1 > 0) { am >>= 1; bm >>= 1; if (am == 0 && x0 != 0) lsbc++; if (bm == 0 && x1 != 0) lsbc++; }
                 bits += (imin(am, 1) + imin(bm, 1)) * 2048;
             }
-            cd[p] = (uint32_t)tin | ((uint32_t)(maxlev + 1) << 10) | ((uint32_t)sym << 16);
-            const int pk2 = lc3t_ac_ctx_lut[tin + imin(imax(maxlev, 0), 3) * 1024];
-            const uint32_t cl = lc3t_ac_cum[pk2 * 18 + sym], ch = lc3t_ac_cum[pk2 * 18 + sym + 1];
-            cf[p] = cl | ((ch - cl) << 16);
+            const int pk2 = lc3t_ac_ctx_lut[tin + imin(imax(maxlev, 0), 3) * 1024];     /* model of the final symbol (R/ari_codec.c:723-727) */
+            cdw[p] = (uint32_t)tin | ((uint32_t)(maxlev + 1) << 10) | ((uint32_t)pk2 << 16) | ((uint32_t)sym << 22);
         }
         const int incl = wave_incl_scan_i(bits, lane) + base;
         const unsigned long long ok = __ballot(act && mode >= 0 && (a0 != 0 || b0 != 0) && incl <= target * 2048);
@@ -1428,44 +1497,46 @@ __device__ __forceinline__ void gain_adjust(const lc3d_plan* __restrict__ P, Wav
     }
 }
 
-/* ---- noise factor R/noise_factor.c:13-108 ---- */
-STAGE void st_noise_factor(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ C, WaveLds& L, int lane, int bw_bin)
+/* ---- noise factor R/noise_factor.c:13-108 ----
+ * Pass 1 finds the zero lines (ballots) and their count / index sum; pass 2 accumulates |x/gg| over them in index order,
+ * the serial float sums fed from lane registers with readlane (no list in LDS). */
+STAGE void st_noise_factor(const lc3d_plan* __restrict__ P, WaveLds& L, int lane, int bw_bin)
 {
-    const int width = PI(dms) == 100 ? 8 : 4, first = PI(dms) == 100 ? 24 : PI(dms) == 50 ? 12 : 6, hw = (width - 2) / 2;
+    const int dms = PI(dms);
+    const int width = dms == 100 ? 8 : 4, first = dms == 100 ? 24 : dms == 50 ? 12 : 6, hw = (width - 2) / 2;
     const float gg = unif(L.fsc[F_GAIN]);
     const int* xq = XQ(L);
-    float* val = L.B; uint16_t* zk = ZKL(L);
     int nz = 0, sumz = 0;
-    for (int k0 = first; k0 < bw_bin; k0 += WAVE) {
-        const int k = k0 + lane;
+    unsigned long long zm[8];                       /* zero-line masks of up to 8 chunks of 64 bins (bw_bin <= 480) */
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        const int k = first + 64 * c + lane;
         bool allz = false;
         if (k < bw_bin) {
             allz = true;
             const int lo = k - hw, hi = imin(bw_bin - 1, k + hw);
             for (int i = lo; i <= hi; i++) if (xq[i] != 0) allz = false;
         }
-        const unsigned long long mk = __ballot(allz);
-        if (allz) {
-            const int pos = nz + __popcll(mk & ((1ull << lane) - 1ull));
-            val[pos] = fabsf(L.A[k] / gg); zk[pos] = (uint16_t)(k + 1);
-        }
-        nz += __popcll(mk);
+        zm[c] = __ballot(allz);
+        nz += __popcll(zm[c]);
         sumz += uni(wave_sum_i(allz ? k + 1 : 0));
     }
-    LSYNC();
-    float fac = 0;
-    const bool split = CI(nbytes) <= 20 && PI(dms) == 100 && nz > 0;
+    const bool split = CI(nbytes) <= 20 && dms == 100 && nz > 0;
     const int msplit = split ? sumz / nz : 0x7fffffff;
     float m1 = 0, m2 = 0; int j1 = 0;
-    for (int i0 = 0; i0 < nz; i0 += WAVE) {         /* serial float sums in index order, operands through readlane */
-        const int i = i0 + lane;
-        const float v = i < nz ? val[i] : 0.0f;
-        const bool lowgrp = i < nz && (int)zk[i] <= msplit;
-        const unsigned long long lm = __ballot(lowgrp);
-        const int cnt = imin(WAVE, nz - i0);
-        for (int k = 0; k < cnt; k++) { const float t = rl_f(v, k); if ((lm >> k) & 1ull) m1 += t; else m2 += t; }
-        j1 += __popcll(lm);
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        const int k = first + 64 * c + lane;
+        const float v = k < bw_bin ? fabsf(L.A[k] / gg) : 0.0f;
+        unsigned long long m = zm[c];
+        const int kbase = first + 64 * c;
+        while (m) {
+            const int b = __ffsll((long long)m) - 1; m &= m - 1;
+            const float t = rl_f(v, b);
+            if (kbase + b + 1 <= msplit) { m1 += t; j1++; } else m2 += t;
+        }
     }
+    float fac = 0;
     if (sumz > 0) fac = m1 / (float)nz;              /* without the split every line is in the "low" group */
     if (split) { const float n1 = m1 / (float)j1, n2 = m2 / (float)(nz - j1); fac = n1 < n2 ? n1 : n2; }
     float idx = (float)round((double)(8 - 16 * fac));
@@ -1474,50 +1545,37 @@ STAGE void st_noise_factor(const lc3d_plan* __restrict__ P, const lc3d_chan* __r
     LSYNC();
 }
 
-/* ---- residual coding R/residual_coding.c:13-75 ---- */
+/* ---- residual coding R/residual_coding.c:13-75 ----
+ * The n-th non-zero coefficient (in bin order) owns residual bit n; a ballot prefix count gives n, so every lane decides and
+ * stores its own bit.  High-resolution mode repeats the sweep with a halved offset (up to 20 times). */
 STAGE void st_residual(const lc3d_plan* __restrict__ P, WaveLds& L, int lane, int targetBits, int nBits)
 {
-    uint16_t* nzi = (uint16_t*)L.B;
     const int* xq = XQ(L);
     const float gain = unif(L.fsc[F_GAIN]);
-    uint8_t* res = RESB(L);
-    int nnz = 0;
-    for (int k0 = 0; k0 < PI(ylen); k0 += WAVE) {
-        const int k = k0 + lane;
-        const bool nzq = k < PI(ylen) && xq[k] != 0;
-        const unsigned long long mk = __ballot(nzq);
-        if (nzq) nzi[nnz + __popcll(mk & ((1ull << lane) - 1ull))] = (uint16_t)k;
-        nnz += __popcll(mk);
-    }
+    unsigned* res = (unsigned*)RESB(L);
+    const int ylen = PI(ylen), hr = PI(hrmode);
     int m = targetBits - nBits + 4;
-    if (PI(hrmode)) m += 10;
-    const int iter_max = PI(hrmode) ? 20 : 1;
-    for (int i = lane; i < 160; i += WAVE) ((uint32_t*)res)[i] = 0;
+    if (hr) m += 10;
+    const int iter_max = hr ? 20 : 1;
+    for (int i = lane; i < 160; i += WAVE) res[i] = 0;
     LSYNC();
     int n = 0, iter = 0; float offset = .25f;
     while (iter < iter_max && n < m) {
-        for (int k0 = 0; k0 < nnz && n < m; k0 += WAVE) {
+        for (int k0 = 0; k0 < ylen && n < m; k0 += WAVE) {
             const int k = k0 + lane;
-            const bool act = k < nnz && (n + lane) < m;
-            int bit = 0;
-            if (act) {
-                const int id = nzi[k];
-                const float x = L.A[id];
-                if (x >= (float)xq[id] * gain) { bit = 1; L.A[id] = x - gain * offset; } else { L.A[id] = x + gain * offset; }
+            const int q = k < ylen ? xq[k] : 0;
+            const unsigned long long mk = __ballot(q != 0);
+            const int pos = n + __popcll(mk & ((1ull << lane) - 1ull));
+            if (q != 0 && pos < m) {
+                const float x = L.A[k];
+                if (x >= (float)q * gain) { atomicOr(&res[pos >> 5], 1u << (pos & 31)); L.A[k] = x - gain * offset; }
+                else L.A[k] = x + gain * offset;
             }
-            const unsigned long long bm = __ballot(bit);
-            const int cnt = __popcll(__ballot(act));
-            if (lane < 3) {                          /* 64 fresh bits at bit offset n: three word-granular ORs */
-                const int sh = n & 31, w0 = n >> 5;
-                const unsigned lo = (unsigned)bm, hi = (unsigned)(bm >> 32);
-                const unsigned v = lane == 0 ? lo << sh : lane == 1 ? ((sh ? lo >> (32 - sh) : 0u) | (hi << sh)) : (sh ? hi >> (32 - sh) : 0u);
-                if (v && w0 + lane < 160) atomicOr(&((unsigned*)res)[w0 + lane], v);
-            }
-            n += cnt;
-            LSYNC();
+            n = imin(m, n + __popcll(mk));
         }
         iter++; offset *= .5f;
     }
+    LSYNC();
     if (lane == 0) L.isc[I_NRES] = n;
     LSYNC();
 }
@@ -1594,12 +1652,14 @@ __device__ __forceinline__ void ari_encode(AriSt& w, uint8_t* bytes, int lane, i
 STAGE void st_bitstream(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ C, WaveLds& L, int lane)
 {
     int* isc = L.isc;
-    uint8_t* bytes = L.bytes;
+    uint8_t* bytes = BYTES(L);
+    for (int i = lane; i < 104; i += WAVE) ((uint32_t*)bytes)[i] = 0;      /* the spectrum in A is dead from here on */
+    LSYNC();
     const int nbytes = CI(nbytes);
     const int nfilt = uni(isc[I_TNS_NF]);
     const int lastnz = uni(isc[I_LASTNZ]), lsbMode = uni(isc[I_LSB]), nres = uni(isc[I_NRES]);
     const int bw_idx = uni(isc[I_BW]), gg = uni(isc[I_GG]), fac_ns = uni(isc[I_FACNS]);
-    const int* xq = XQ(L); const uint32_t* cd = CD(L); const uint32_t* cf = CF(L); uint8_t* resb = RESB(L);
+    const int* xq = XQ(L); const uint32_t* cdw = CDW(L); uint8_t* resb = RESB(L);
     /* ---- side information: fields appended LSB-first into a 128-bit accumulator (uniform), R/enc_entropy.c:25-87 ---- */
     unsigned long long slo = 0, shi = 0; int Q = 0;
 #define SIDE(val_, n_) do { unsigned long long v_ = (unsigned long long)(unsigned)(val_) & (((n_) >= 32) ? 0xffffffffull : ((1ull << (n_)) - 1ull)); \
@@ -1657,7 +1717,9 @@ STAGE void st_bitstream(const lc3d_plan* __restrict__ P, const lc3d_chan* __rest
     int nl = 0;                                   /* LSB-mode list length */
     for (int c0 = 0; c0 < ntup; c0 += WAVE) {
         const int p = c0 + lane; const bool act = p < ntup;
-        const uint32_t cdv = act ? cd[p] : 0u, cfv = act ? cf[p] : 0u;
+        const uint32_t cdv = act ? cdw[p] : 0u;
+        unsigned cfv = 0;
+        if (act) { const uint16_t* q = &lc3t_ac_cum[((cdv >> 16) & 63) * 18 + ((cdv >> 22) & 31)]; cfv = q[0] | ((unsigned)(q[1] - q[0]) << 16); }
         const int x0 = act ? xq[2 * p] : 0, x1 = act ? xq[2 * p + 1] : 0;
         const int a0 = x0 < 0 ? -x0 : x0, b0 = x1 < 0 ? -x1 : x1;
         const int ctx = cdv & 1023, maxlev = act ? (int)((cdv >> 10) & 63) - 1 : -1;
@@ -1757,7 +1819,7 @@ STAGE void st_bitstream(const lc3d_plan* __restrict__ P, const lc3d_chan* __rest
 /* ------------------------------------------------------------------------------------------------ */
 /* the kernel: one wave per channel-stream, frames in time order  (frame driver R/enc_lc3_fl.c:13-160) */
 /* ------------------------------------------------------------------------------------------------ */
-extern "C" __global__ void __launch_bounds__(WAVE)
+extern "C" __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4, 4)))
 lc3_encode_kernel(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans, float* __restrict__ state,
                   const void* __restrict__ pcm, int bitdepth, int T, uint8_t* __restrict__ out, int out_stride, int ncs,
                   lc3d_trace* __restrict__ trace)
@@ -1766,8 +1828,8 @@ lc3_encode_kernel(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__
     const int lane = threadIdx.x;
     const int cs = blockIdx.x;
     if (cs >= ncs) return;
-    if (lane < 48) L.pc[lane] = ((const int*)P)[lane];
-    if (lane < 16) L.cc[lane] = ((const int*)&chans[cs])[lane];
+    if (lane < 42) L.pc[lane] = ((const int*)P)[lane];
+    if (lane < 14) L.cc[lane] = ((const int*)&chans[cs])[lane];
     LSYNC();
     const lc3d_chan* __restrict__ C = &chans[cs];
     const int N = PI(N), channels = PI(channels), ml = N - PI(la);
@@ -1778,7 +1840,7 @@ lc3_encode_kernel(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__
     for (int i = lane; i < MEMCAP; i += WAVE) L.xbuf[i] = stp[LC3D_ST_XPREV + i];
     for (int i = lane; i < 384; i += WAVE) L.h12[i] = stp[LC3D_ST_H12 + i];
     for (int i = lane; i < 194; i += WAVE) L.h6[i] = stp[LC3D_ST_H6 + i];
-    if (lane < 16) L.fsc[lane] = stp[LC3D_ST_SCAL + lane];
+    if (lane < 12) L.fsc[lane] = stp[LC3D_ST_SCAL + lane];
     if (lane < 16) L.isc[lane] = ((const int*)stp)[LC3D_ST_SCAL + 16 + lane];
     LSYNC();
     if (CI(reset_attack) && lane == 0) { L.fsc[F_ATT_M0] = 0; L.fsc[F_ATT_M1] = 0; L.fsc[F_ATT_ACC] = 0; L.isc[I_ATT_POS] = 0; L.isc[I_ATT_FLAG] = 0; }
@@ -1805,7 +1867,6 @@ lc3_encode_kernel(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__
             const float sc = bitdepth == 24 ? 256.0f : 65536.0f;
             for (int i = lane; i < N; i += WAVE) XCUR(L)[i] = (float)p[i] / sc;
         }
-        for (int i = lane; i < 104; i += WAVE) ((uint32_t*)L.bytes)[i] = 0;
         LSYNC();
         TICK(0);
 
@@ -1873,7 +1934,7 @@ lc3_encode_kernel(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__
             if (change) st_quantize(P, C, L, lane, 0, tbq);
         }
         TICK(13);
-        st_noise_factor(P, C, L, lane, bw_bin);
+        st_noise_factor(P, L, lane, bw_bin);
         TICK(14);
         if (tr) { if (lane == 0) { tr->gain = L.fsc[F_GAIN]; tr->gg_idx = L.isc[I_GG]; tr->gain_change = L.isc[I_CHANGE]; tr->nbits = L.isc[I_NBITS]; tr->nbits2 = L.isc[I_NBITS2];
                                    tr->lastnz = L.isc[I_LASTNZ]; tr->lsb_mode = L.isc[I_LSB]; tr->fac_ns = L.isc[I_FACNS]; }
@@ -1887,7 +1948,7 @@ lc3_encode_kernel(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__
         if (tr && lane == 0) { tr->n_res_bits = L.isc[I_NRES]; tr->bp_side = L.isc[I_BP_SIDE]; tr->mask_side = L.isc[I_MASK_SIDE]; }
         /* ---- bytes out ---- */
         uint8_t* o = out + ((size_t)strm * T + t) * out_stride + CI(out_off);
-        for (int i = lane; i < CI(nbytes); i += WAVE) o[i] = L.bytes[i];
+        for (int i = lane; i < CI(nbytes); i += WAVE) o[i] = BYTES(L)[i];
         LSYNC();
         TICK(17);
     }
@@ -1898,7 +1959,7 @@ lc3_encode_kernel(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__
     for (int i = lane; i < MEMCAP; i += WAVE) stp[LC3D_ST_XPREV + i] = L.xbuf[i];
     for (int i = lane; i < 384; i += WAVE) stp[LC3D_ST_H12 + i] = L.h12[i];
     for (int i = lane; i < 194; i += WAVE) stp[LC3D_ST_H6 + i] = L.h6[i];
-    if (lane < 16) stp[LC3D_ST_SCAL + lane] = L.fsc[lane];
+    if (lane < 12) stp[LC3D_ST_SCAL + lane] = L.fsc[lane];
     if (lane < 16) ((int*)stp)[LC3D_ST_SCAL + 16 + lane] = L.isc[lane];
     (void)ml;
 }
