@@ -267,7 +267,6 @@ LC3_Error lc3plus_enc_batch_create(lc3plus_batch** out, int n_streams, int sampl
     geom_init(&b->g, samplerate, channels);
     b->g.dms = (int)(frame_ms * 10); b->g.frame_ms = frame_ms; b->g.hrmode = hrmode > 0;
     geom_update(&b->g);
-    if (b->g.fs_idx == 5 && b->g.hrmode == 0) { free(b); return LC3_HRMODE_ERROR; }
     if (!geom_supported(&b->g)) {
         fprintf(stderr, "lc3plus_hip: %d Hz / %.1f ms%s is not built into the gfx950 kernels yet\n", samplerate, frame_ms, hrmode ? " hr" : "");
         free(b); return LC3_ERROR;

@@ -45,7 +45,7 @@ def synth_pcm_device(torch, B, T, dev, seed):
     return x.round().clamp(-32768, 32767).to(torch.int16).reshape(B, T, N).contiguous()
 
 
-def cpu_baseline(n_streams=512, T=64):
+def cpu_baseline(n_streams=2048, T=64):
     """ETSI reference (oracle/_ref, kind 'reference') or the C restatement (kind 'port') timed on the host cores.
     Bounded sample: n_streams x T frames of the same workload, one worker process per core (streams are independent)."""
     import numpy as np
@@ -109,7 +109,10 @@ def main():
     dev = torch.device("cuda", local)
 
     B, T = a.streams, a.frames
-    pcm = synth_pcm_device(torch, B, T, dev, seed=1234 + rank)
+    from audio_codec_amd.sharding import stream_block
+    first, last = stream_block(rank, world, B * world)          # weak scaling: every rank owns B of the B*world streams
+    assert last - first == B
+    pcm = synth_pcm_device(torch, B, T, dev, seed=1234 + first)
     batch = audio_codec_amd.Batch(B, FS, 1, FRAME_MS, 0, [BITRATE] * B, device=local)
     stride = batch.stride
     out = torch.zeros(B, T, stride, dtype=torch.uint8, device=dev)

@@ -1,0 +1,108 @@
+"""CPU tests of the product's host side: the C-ABI library loads, exports every symbol the public headers declare,
+derives the same configuration as the reference (via the oracle restatement), and refuses to encode without a GPU
+(no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import audio_codec_amd
+from lc3_harness import ORACLE_DIR, build_oracle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    audio_codec_amd.build()
+    L = audio_codec_amd.load_library()
+    L.lc3_enc_set_frame_ms.argtypes = [C.c_void_p, C.c_float]
+    return L
+
+
+def test_exports_every_declared_symbol(lib):
+    declared = set()
+    for h in ("lc3.h", "lc3plus_batch.h"):
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        declared |= set(re.findall(r"\b(lc3(?:plus)?_\w+)\s*\(", text))
+    assert len(declared) >= 30
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, missing
+    assert set(audio_codec_amd.api.EXPORTS) <= declared | {"lc3_enc_fl"}
+
+
+def test_version_and_support_queries(lib):
+    assert lib.lc3_version() == (1 << 16) | (4 << 8) | 10
+    assert [lib.lc3_samplerate_supported(s) for s in (8000, 16000, 24000, 32000, 44100, 48000, 96000, 22050)] == [1] * 7 + [0]
+    assert [lib.lc3_channels_supported(c) for c in (0, 1, 2, 3)] == [0, 1, 1, 0]
+
+
+def _oracle():
+    build_oracle()
+    o = C.CDLL(os.path.join(ORACLE_DIR, "liblc3_oracle.so"))
+    o.lc3o_enc_set_frame_ms.argtypes = [C.c_void_p, C.c_float]
+    return o
+
+
+CASES = [(fs, ms, hr, br, ch)
+         for fs in (8000, 16000, 24000, 32000, 44100, 48000, 96000)
+         for ms in (2.5, 5.0, 10.0, 7.5)
+         for hr in (0, 1)
+         for br, ch in ((8000, 1), (16000, 1), (64000, 1), (128000, 2), (256000, 1), (320000, 1), (400000, 1), (700000, 2))]
+
+
+def test_configuration_matches_reference_derivation(lib):
+    """Error codes and derived sizes of lc3_enc_init / set_frame_ms / set_hrmode / set_bitrate (R/lc3.c:102-208,
+    R/setup_enc_lc3.c:196-375) against the oracle restatement, which is itself pinned to the compiled reference."""
+    o = _oracle()
+    for fs, ms, hr, br, ch in CASES:
+        pb = C.create_string_buffer(lib.lc3_enc_get_size(48000, 2)); p = C.cast(pb, C.c_void_p)
+        ob = C.create_string_buffer(o.lc3o_enc_sizeof()); q = C.cast(ob, C.c_void_p)
+        got = [lib.lc3_enc_init(p, fs, ch), lib.lc3_enc_set_frame_ms(p, ms), lib.lc3_enc_set_hrmode(p, hr), lib.lc3_enc_set_bitrate(p, br)]
+        want = [o.lc3o_enc_init(q, fs, ch), o.lc3o_enc_set_frame_ms(q, ms), o.lc3o_enc_set_hrmode(q, hr), o.lc3o_enc_set_bitrate(q, br)]
+        assert got == want, (fs, ms, hr, br, ch, got, want)
+        if got[3] == 0:
+            g2 = [lib.lc3_enc_get_num_bytes(p), lib.lc3_enc_get_input_samples(p), lib.lc3_enc_get_delay(p), lib.lc3_enc_get_real_bitrate(p)]
+            w2 = [o.lc3o_enc_get_num_bytes(q), o.lc3o_enc_get_input_samples(q), o.lc3o_enc_get_delay(q), o.lc3o_enc_get_real_bitrate(q)]
+            assert g2 == w2, (fs, ms, hr, br, ch, g2, w2)
+        lib.lc3_free_encoder_structs(p)
+
+
+def test_null_and_misuse(lib):
+    assert lib.lc3_enc_init(None, 48000, 1) == 3
+    assert lib.lc3_enc_get_size(12345, 1) == 0 and lib.lc3_enc_get_size(48000, 5) == 0
+    pb = C.create_string_buffer(lib.lc3_enc_get_size(48000, 1)); p = C.cast(pb, C.c_void_p)
+    assert lib.lc3_enc_init(p, 48000, 1) == 0
+    assert lib.lc3_enc_get_real_bitrate(p) == 12                      # LC3_BITRATE_UNSET_ERROR
+    assert lib.lc3_enc_set_bandwidth(p, 30000) == 18                  # LC3_BW_WARNING
+    assert lib.lc3_enc_set_bitrate(p, 0) == 6 and lib.lc3_enc_set_bitrate(p, 64000) == 0
+    assert lib.lc3_enc_set_frame_ms(p, 5.0) == 13                     # LC3_BITRATE_SET_ERROR
+    nb = C.c_int(0)
+    assert lib.lc3_enc_fl(p, None, 16, None, C.byref(nb)) == 3
+
+
+def test_no_cpu_fallback_without_gpu(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(audio_codec_amd.LC3Error):
+        audio_codec_amd.Batch(2, 48000, 1, 10.0, 0, [64000, 64000])
+    e = audio_codec_amd.Encoder(48000, 1, 10.0, 0, 64000)          # configuration works on the host ...
+    with pytest.raises(audio_codec_amd.LC3Error):
+        e.encode(np.zeros((1, 480), np.int16))                       # ... encoding does not: the HIP path is the only path
+
+
+def test_batch_argument_validation(lib):
+    h = C.c_void_p()
+    br = (C.c_int * 2)(64000, 64000)
+    f = lib.lc3plus_enc_batch_create
+    assert f(C.byref(h), 2, 12345, 1, 10.0, 0, br, -1) == 4
+    assert f(C.byref(h), 2, 48000, 3, 10.0, 0, br, -1) == 5
+    assert f(C.byref(h), 2, 48000, 1, 7.5, 0, br, -1) == 9
+    assert f(C.byref(h), 2, 32000, 1, 10.0, 1, br, -1) == 4
+    assert f(C.byref(h), 2, 96000, 1, 10.0, 0, br, -1) == 1      # 96 kHz forces hrmode (R/setup_enc_lc3.c:93-96); N = 960 is not built yet
+    bad = (C.c_int * 2)(64000, 1000)
+    assert f(C.byref(h), 2, 48000, 1, 10.0, 0, bad, -1) in (1, 6)   # bitrate error (6) unless no device was found first (1)

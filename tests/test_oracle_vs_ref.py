@@ -62,3 +62,17 @@ def test_api_error_codes_match():
         got = [o.lc3o_enc_init(q, fs, 1), o.lc3o_enc_set_frame_ms(q, ms), o.lc3o_enc_set_hrmode(q, hr), o.lc3o_enc_set_bitrate(q, br),
                o.lc3o_enc_get_num_bytes(q), o.lc3o_enc_get_input_samples(q), o.lc3o_enc_get_delay(q)]
         assert got == want, (fs, ms, hr, br, got, want)
+
+
+@pytest.mark.parametrize("fs,ms,hr,N,rates", [
+    (48000, 5.0, 0, 240, [32000, 64000, 96000, 128000, 256000]),
+    (24000, 10.0, 0, 240, [16000, 32000, 64000, 128000]),
+    (96000, 5.0, 1, 480, [256000, 400000]),
+    (48000, 10.0, 1, 480, [128000, 256000, 400000]),
+    (48000, 5.0, 1, 240, [160000, 320000]),
+    (44100, 10.0, 0, 480, [32000, 64000, 128000]),
+])
+def test_other_geometries(fs, ms, hr, N, rates):
+    pcm = synth_pcm(len(rates), 40, N, fs if fs != 44100 else 48000, seed=13)
+    for r, o in zip(ref_encode_streams(pcm, fs, ms, hr, rates), oracle_encode_streams(pcm, fs, ms, hr, rates)):
+        assert (r == o).all()
