@@ -125,3 +125,59 @@ def test_empty_and_edge_inputs():
         want = oracle_encode_streams(pcm, 48000, 10.0, 0, [16000, 320000], portable_math=True)
         same, tot = _frames_equal(got, want)
         assert same == tot
+
+
+def _write_wav(path, pcm_interleaved, fs, channels, bits):
+    import wave
+    w = wave.open(str(path), "wb")
+    w.setnchannels(channels); w.setsampwidth(bits // 8); w.setframerate(fs)
+    if bits == 16:
+        w.writeframes(pcm_interleaved.astype("<i2").tobytes())
+    else:                                     # 24-bit little endian
+        v = pcm_interleaved.astype(np.int32)
+        b = np.stack([(v & 0xff), (v >> 8) & 0xff, (v >> 16) & 0xff], axis=-1).astype(np.uint8)
+        w.writeframes(b.tobytes())
+    w.close()
+
+
+def _container(frames, fs, bitrate, channels, frame_ms, nsamples, hrmode):
+    """The .lc3plus container of R/codec_exe.c:651-661,742-748 around a list of frame payloads."""
+    hdr = np.array([0xcc1c, 20, fs // 100, bitrate // 100, channels, int(frame_ms * 100), 0, nsamples & 0xffff, nsamples >> 16, hrmode], np.uint16)
+    out = [hdr.tobytes()]
+    for f in frames:
+        out.append(np.uint16(len(f)).tobytes()); out.append(bytes(f))
+    return b"".join(out)
+
+
+@pytest.mark.parametrize("channels,bits,bitrate", [(1, 16, 64000), (2, 24, 128000)])
+def test_cli_front_end_writes_the_reference_container(tmp_path, channels, bits, bitrate):
+    """tools/lc3plus_enc_cli (C, on the C ABI) against the ETSI CLI (oracle/_ref/LC3plus, when built) and the oracle."""
+    import subprocess
+    from lc3_harness import ORACLE_DIR
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cli = os.path.join(root, "tools", "lc3plus_enc_cli")
+    if not os.path.exists(cli):
+        subprocess.check_call(["make", "-s", "-C", root, "cli"])
+    nsamp = 480 * 37 + 123                                      # partial last frame: zero padded (R/codec_exe.c:329-338)
+    pcm = synth_pcm(channels, 38, 480, 48000, seed=31).reshape(channels, -1)[:, :nsamp]
+    if bits == 24:
+        pcm = pcm.astype(np.int32) * 200 + 7
+    wav = tmp_path / "in.wav"
+    _write_wav(wav, pcm.T.reshape(-1), 48000, channels, bits)
+    ours = tmp_path / "ours.lc3plus"
+    subprocess.check_call([cli, "-E", "-q", str(wav), str(ours), str(bitrate)])
+    got = open(ours, "rb").read()
+    # expected container from the oracle (same math as the device)
+    o = Oracle(48000, channels, 10.0, 0, bitrate, portable_math=True)
+    padded = np.zeros((channels, 38 * 480), pcm.dtype); padded[:, :nsamp] = pcm
+    frames = [o.encode(padded[:, t * 480:(t + 1) * 480], bits) for t in range(38)]
+    assert got == _container(frames, 48000, bitrate, channels, 10.0, nsamp, 0)
+    ref_cli = os.path.join(ORACLE_DIR, "_ref", "LC3plus")
+    if os.path.exists(ref_cli):                                 # the real thing, when it travelled with the snapshot
+        theirs = tmp_path / "ref.lc3plus"
+        subprocess.check_call([ref_cli, "-E", "-q", str(wav), str(theirs), str(bitrate)], stdout=subprocess.DEVNULL)
+        ref = open(theirs, "rb").read()
+        assert len(ref) == len(got) and ref[:20] == got[:20]
+        fr = 2 + o.nbytes
+        same = sum(ref[20 + i * fr:20 + (i + 1) * fr] == got[20 + i * fr:20 + (i + 1) * fr] for i in range(38))
+        assert same >= 37, same
