@@ -65,8 +65,9 @@ static void geom_update(geom_t* g)                                        /* R/s
     if (g->tab) { g->nbands = g->tab->nbands; g->la = g->tab->la_zeros; }
 }
 
-/* the kernels are built for frame lengths up to LC3D_MAX_N whose N/2-point DFT is 240 (15x16) or 120 (8x3x5) */
-static int geom_supported(const geom_t* g) { return g->tab && g->N <= LC3D_MAX_N && (g->N == 480 || g->N == 240); }
+/* the kernels are built for frame lengths up to LC3D_MAX_N whose N/2-point DFT is 240 (15x16) or 120 (8x3x5) and an MDCT
+ * overlap memory of at most 300 samples (excludes 96 kHz / 5 ms: N = 480 with 120 leading zeros) */
+static int geom_supported(const geom_t* g) { return g->tab && g->N <= LC3D_MAX_N && (g->N == 480 || g->N == 240) && g->N - g->la <= 300; }
 
 /* R/setup_enc_lc3.c:196-375: bitrate -> per-channel budgets.  Returns an LC3_Error. */
 static LC3_Error derive_bitrate(const geom_t* g, int bitrate, lc3d_chan* ch /* [channels] */)

@@ -69,7 +69,7 @@ struct __attribute__((aligned(16))) WaveLds {
 #define XCUR(L) (&(L).xbuf[MEMCAP])
 #define XQ(L)   ((int*)&(L).xbuf[MEMCAP])
 #define SPEC(L) ((L).A)
-#define BYTES(L) ((uint8_t*)(L).A)            /* 416 bytes, valid from the bitstream stage to the copy-out */
+#define BYTES(L) ((uint8_t*)(L).A)            /* up to 640 bytes, valid from the bitstream stage to the copy-out */
 #define CDW(L)  ((uint32_t*)&(L).sm[0])      /* per 2-tuple: ctx(10) | maxlev+1 (6) | pki of the final symbol (6) | sym (5) */
 #define RESB(L) ((uint8_t*)&(L).sm[240])     /* 640 bytes: residual bits / LSB-mode list (bit-packed, LSB first) */
 
@@ -317,19 +317,26 @@ STAGE void st_resample(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
             d[h] = mac;
         }
     }
-    /* biquad in double, strictly serial (R/resamp12k8.c:60-74): the x-only products are formed per lane, the recurrence reads
-     * them with readlane, the outputs are dropped back into their lane */
+    /* biquad in double, strictly serial (R/resamp12k8.c:60-74): the x-only products b_k*x are formed per lane and parked in LDS
+     * (A and sm are idle here), the recurrence streams them back with uniform-address reads (LDS issue, not VALU issue) */
     const double b0 = lc3t_hp50_b[0], b1 = lc3t_hp50_b[1], b2 = lc3t_hp50_b[2], a1 = lc3t_hp50_a[1], a2 = lc3t_hp50_a[2];
+    double* q0 = (double*)L.A; double* q1 = (double*)L.sm; double* q2 = q1 + 128;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int n = lane + 64 * h;
+        if (n < len12) { const double x = (double)d[h]; q0[n] = b0 * x; q1[n] = b1 * x; q2[n] = b2 * x; }
+    }
+    LSYNC();
     double u11 = (double)L.fsc[F_HP0], u21 = (double)L.fsc[F_HP1];
     float y[2] = {0, 0};
 #pragma unroll
     for (int h = 0; h < 2; h++) {
-        const double x = (double)d[h], q0 = b0 * x, q1 = b1 * x, q2 = b2 * x;
         const int cnt = imin(len12 - 64 * h, 64);
+#pragma unroll 4
         for (int i = 0; i < cnt; i++) {
-            const double y1 = (rl_d(q0, i) + u11);
-            const double u1 = (rl_d(q1, i) + u21) - a1 * y1;
-            const double u2 = rl_d(q2, i) - a2 * y1;
+            const double y1 = (q0[64 * h + i] + u11);
+            const double u1 = (q1[64 * h + i] + u21) - a1 * y1;
+            const double u2 = q2[64 * h + i] - a2 * y1;
             u11 = u1; u21 = u2;
             y[h] = (lane == i) ? (float)y1 : y[h];
         }
@@ -346,13 +353,17 @@ STAGE void st_resample(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
     LSYNC();
 }
 
-/* normalised correlation at lag T over acf <= 64 samples (R/olpa.c:104-114): serial float sums fed by readlane */
-__device__ __forceinline__ float olpa_normcorr(const float* s6, int acf, int T, int lane, float eps)
+/* normalised correlation at lag T over acf <= 64 samples (R/olpa.c:104-114): the three serial float sums run in all lanes,
+ * the products come back from LDS scratch (A) with uniform-address reads */
+__device__ __forceinline__ float olpa_normcorr(WaveLds& L, const float* s6, int acf, int T, int lane, float eps)
 {
-    const float a = lane < acf ? s6[lane] : 0.0f, b = lane < acf ? s6[lane - T] : 0.0f;
-    const float p0 = a * b, p1 = b * b, p2 = a * a;
+    float* pr = L.A;
+    if (lane < acf) { const float a = s6[lane], b = s6[lane - T]; pr[lane] = a * b; pr[64 + lane] = b * b; pr[128 + lane] = a * a; }
+    LSYNC();
     float s0 = 0, s1 = 0, s2 = 0;
-    for (int i = 0; i < acf; i++) { s0 += rl_f(p0, i); s1 += rl_f(p1, i); s2 += rl_f(p2, i); }
+#pragma unroll 8
+    for (int i = 0; i < acf; i++) { s0 += pr[i]; s1 += pr[64 + i]; s2 += pr[128 + i]; }
+    LSYNC();
     s1 = s1 * s2;
     s1 = sqrtf(s1) + eps;
     const float nc = s0 / s1;
@@ -396,14 +407,14 @@ STAGE void st_olpa(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
     wave_argmax_first(best, besti, 64);
     int T0 = uni(besti) + 17;
     LSYNC();
-    float nc = olpa_normcorr(s6, acf, T0, lane, PF(c_1em5_a));
+    float nc = olpa_normcorr(L, s6, acf, T0, lane, PF(c_1em5_a));
     const int old = uni(L.isc[I_OLPA_PITCH]);
     const int lo = imax(17, old - 4), hi = imin(114, old + 4), cnt = hi - lo + 1;
     float v = (lane & 15) < cnt ? R0[lo - 17 + (lane & 15)] : -INFINITY; int vi = lane & 15;
     wave_argmax_first(v, vi, 16);
     const int T02 = uni(vi) + lo;
     if (T02 != T0) {
-        const float nc2 = olpa_normcorr(s6, acf, T02, lane, PF(c_1em5_a));
+        const float nc2 = olpa_normcorr(L, s6, acf, T02, lane, PF(c_1em5_a));
         if ((double)nc2 > ((double)nc * 0.85)) { T0 = T02; nc = nc2; }
     }
     if (lane == 0) { L.isc[I_OLPA_PITCH] = T0; L.isc[I_T0] = (int)(T0 * 2.0); L.fsc[F_NC] = nc; }
@@ -427,14 +438,16 @@ STAGE void st_ltpf(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict_
         const int t_min = t0_min - 4, t_max = t0_max + 4, nl = t_max - t_min + 1;
         float sum1 = 0, sum2 = 0;
         {   /* R/ltpf_coder.c:74-78: two serial sums over acf <= 128 terms, products per lane */
+            float* pr = L.A;
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 const int j = lane + 64 * h;
-                const float a = j < acf ? x[j] : 0.0f, b = j < acf ? x[j - t_min] : 0.0f;
-                const float pa = a * a, pb = b * b;
-                const int cnt = imin(acf - 64 * h, 64);
-                for (int i = 0; i < cnt; i++) { sum1 += rl_f(pa, i); sum2 += rl_f(pb, i); }
+                if (j < acf) { const float a = x[j], b = x[j - t_min]; pr[j] = a * a; pr[128 + j] = b * b; }
             }
+            LSYNC();
+#pragma unroll 8
+            for (int i = 0; i < acf; i++) { sum1 += pr[i]; sum2 += pr[128 + i]; }
+            LSYNC();
         }
         float* cor = &L.sm[SM_MISC];           /* up to 17 */
         float* cor_int = &L.sm[SM_MISC + 32];  /* up to 36 */
@@ -485,17 +498,20 @@ STAGE void st_ltpf(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict_
         pitch = (float)((double)(float)pitch_int + (double)(float)pitch_fr / 4.0);
         const float* f0 = &lc3t_ltpf_frac[0]; const float* fp = &lc3t_ltpf_frac[4 * pitch_fr];
         float a = 0, b = 0, c = 0;
+        {
+            float* pq = L.A;                        /* 3 x 128 products */
 #pragma unroll
-        for (int h = 0; h < 2; h++) {               /* R/ltpf_coder.c:190-216 */
-            const int n = lane + 64 * h;
-            float cu = 0, pr = 0;
-            if (n < acf) {
-                cu = x[n + 1] * f0[0] + x[n] * f0[1] + x[n - 1] * f0[2];
-                pr = x[n - pitch_int + 1] * fp[0] + x[n - pitch_int] * fp[1] + x[n - pitch_int - 1] * fp[2] + x[n - pitch_int - 2] * fp[3];
+            for (int h = 0; h < 2; h++) {           /* R/ltpf_coder.c:190-216 */
+                const int n = lane + 64 * h;
+                if (n < acf) {
+                    const float cu = x[n + 1] * f0[0] + x[n] * f0[1] + x[n - 1] * f0[2];
+                    const float pr = x[n - pitch_int + 1] * fp[0] + x[n - pitch_int] * fp[1] + x[n - pitch_int - 1] * fp[2] + x[n - pitch_int - 2] * fp[3];
+                    pq[n] = cu * pr; pq[128 + n] = cu * cu; pq[256 + n] = pr * pr;
+                }
             }
-            const float pa = cu * pr, pb = cu * cu, pc = pr * pr;
-            const int cnt = imin(acf - 64 * h, 64);
-            for (int i = 0; i < cnt; i++) { a += rl_f(pa, i); b += rl_f(pb, i); c += rl_f(pc, i); }
+            LSYNC();
+#pragma unroll 8
+            for (int i = 0; i < acf; i++) { a += pq[i]; b += pq[128 + i]; c += pq[256 + i]; }
         }
         b = sqrtf(b * c) + PF(c_1em5_b);
         norm_corr = a / b;
@@ -1315,15 +1331,15 @@ STAGE void st_tns(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__
 
 /* one bisection probe of R/estimate_global_gain.c:97-124 for this lane's candidate offset; the energies come from
  * lane registers (e0: j < 64, e1: j >= 64) through readlane, so the 100-step serial chain never touches LDS */
-__device__ __forceinline__ bool gain_probe(float thr7, float thr50, float e0, float e1, int nq, int cand, float target)
+__device__ __forceinline__ bool gain_probe(float thr7, float thr50, const float* en, int nq, int cand, float target)
 {
     float ener = 0; int iszero = 1;
     const float fc = (float)cand;
 #define GSTEP(ev) do { const float t = (ev) - fc; const bool lo = t < thr7, hi = t > thr50; \
         const float e_c = (float)((double)ener + (2.7) * (28.0 / 20.0)), e_b = (float)((double)ener + 2.0 * (double)t - (50.0) * (28.0 / 20.0)), e_a = ener + t; \
         ener = lo ? (iszero ? ener : e_c) : (hi ? e_b : e_a); iszero = lo ? iszero : 0; } while (0)
-    for (int j = nq - 1; j >= 64; j--) GSTEP(rl_f(e1, j - 64));
-    for (int j = imin(nq, 64) - 1; j >= 0; j--) GSTEP(rl_f(e0, j));
+#pragma unroll 4
+    for (int j = nq - 1; j >= 0; j--) GSTEP(en[j]);
 #undef GSTEP
     return ener > target && iszero == 0;
 }
@@ -1363,7 +1379,7 @@ STAGE void st_gain_estimate(const lc3d_plan* __restrict__ P, const lc3d_chan* __
     else {
         const float g_min = PI(hrmode) == 1 ? x_max / (float)(32768 * 256 - 2) : (float)((double)x_max / (32768 - 0.375));
         ind_min = (float)ceil(28.0 * (double)m_log10f(g_min));
-        float e[2] = {0, 0};
+        float* en = XCUR(L);                         /* X is scratch between TNS and quantisation */
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const int j = lane + 64 * h;
@@ -1371,9 +1387,10 @@ STAGE void st_gain_estimate(const lc3d_plan* __restrict__ P, const lc3d_chan* __
                 const float* x = &L.A[4 * j];
                 float t = x[0] * x[0];
                 t += x[1] * x[1]; t += x[2] * x[2]; t += x[3] * x[3];
-                e[h] = (float)((28.0 / 20.0) * (7 + 10.0 * (double)m_log10f(t + reg_val + PF(c_2m31))));
+                en[j] = (float)((28.0 / 20.0) * (7 + 10.0 * (double)m_log10f(t + reg_val + PF(c_2m31))));
             }
         }
+        LSYNC();
         const float target = (float)((28.0 / 20.0) * (1.4) * (double)nbitsSQ);
         const float thr7 = PF(c_thr7_up), thr50 = PF(c_thr50_dn);
         const int offset0 = 255 + off;
@@ -1382,13 +1399,13 @@ STAGE void st_gain_estimate(const lc3d_plan* __restrict__ P, const lc3d_chan* __
         {
             const int lvl = lane ? ilog2((unsigned)lane) : 0, p = lane - (1 << lvl);
             const int cand = offset0 - (p << (8 - lvl)) - (128 >> lvl);
-            const unsigned long long addback = __ballot(gain_probe(thr7, thr50, e[0], e[1], nq, cand, target));
+            const unsigned long long addback = __ballot(gain_probe(thr7, thr50, en, nq, cand, target));
             int node = 1;
             for (int i = 0; i < 6; i++) { const int nb = ((addback >> node) & 1ull) ? 0 : 1; m += nb << (7 - i); node = 2 * node + nb; }
         }
         {   /* last two steps: lane 0: step 6; lane 1: step 7 if step 6 added back; lane 2: step 7 otherwise */
             const int cand = lane == 0 ? offset0 - m - 2 : lane == 1 ? offset0 - m - 1 : offset0 - m - 3;
-            const unsigned long long addback = __ballot(gain_probe(thr7, thr50, e[0], e[1], nq, cand, target));
+            const unsigned long long addback = __ballot(gain_probe(thr7, thr50, en, nq, cand, target));
             if (addback & 1ull) { if (!(addback & 2ull)) m += 1; }
             else { m += 2; if (!(addback & 4ull)) m += 1; }
         }
@@ -1653,7 +1670,7 @@ STAGE void st_bitstream(const lc3d_plan* __restrict__ P, const lc3d_chan* __rest
 {
     int* isc = L.isc;
     uint8_t* bytes = BYTES(L);
-    for (int i = lane; i < 104; i += WAVE) ((uint32_t*)bytes)[i] = 0;      /* the spectrum in A is dead from here on */
+    for (int i = lane; i < 160; i += WAVE) ((uint32_t*)bytes)[i] = 0;      /* 640 B >= the largest frame (625 B, hrmode); the spectrum in A is dead from here on */
     LSYNC();
     const int nbytes = CI(nbytes);
     const int nfilt = uni(isc[I_TNS_NF]);
