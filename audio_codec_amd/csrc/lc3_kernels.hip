@@ -1331,10 +1331,12 @@ STAGE void st_tns(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__
 
 /* one bisection probe of R/estimate_global_gain.c:97-124 for this lane's candidate offset; the energies come from
  * lane registers (e0: j < 64, e1: j >= 64) through readlane, so the 100-step serial chain never touches LDS */
-__device__ __forceinline__ bool gain_probe(float thr7, float thr50, const float* en, int nq, int cand, float target)
+__device__ __forceinline__ bool gain_probe(float thr7, float thr50, const float* en, int nq, int cand, int cand_min, float target)
 {
     float ener = 0; int iszero = 1;
-    const float fc = (float)cand;
+    const float fc = (float)cand, fmin = (float)cand_min;
+    /* while even the smallest candidate sees en[j] - cand < thr7 and no lane has left the all-zero state, a step is a no-op */
+    while (nq > 0 && en[nq - 1] - fmin < thr7) nq--;
 #define GSTEP(ev) do { const float t = (ev) - fc; const bool lo = t < thr7, hi = t > thr50; \
         const float e_c = (float)((double)ener + (2.7) * (28.0 / 20.0)), e_b = (float)((double)ener + 2.0 * (double)t - (50.0) * (28.0 / 20.0)), e_a = ener + t; \
         ener = lo ? (iszero ? ener : e_c) : (hi ? e_b : e_a); iszero = lo ? iszero : 0; } while (0)
@@ -1399,13 +1401,13 @@ STAGE void st_gain_estimate(const lc3d_plan* __restrict__ P, const lc3d_chan* __
         {
             const int lvl = lane ? ilog2((unsigned)lane) : 0, p = lane - (1 << lvl);
             const int cand = offset0 - (p << (8 - lvl)) - (128 >> lvl);
-            const unsigned long long addback = __ballot(gain_probe(thr7, thr50, en, nq, cand, target));
+            const unsigned long long addback = __ballot(gain_probe(thr7, thr50, en, nq, cand, offset0 - 252, target));
             int node = 1;
             for (int i = 0; i < 6; i++) { const int nb = ((addback >> node) & 1ull) ? 0 : 1; m += nb << (7 - i); node = 2 * node + nb; }
         }
         {   /* last two steps: lane 0: step 6; lane 1: step 7 if step 6 added back; lane 2: step 7 otherwise */
             const int cand = lane == 0 ? offset0 - m - 2 : lane == 1 ? offset0 - m - 1 : offset0 - m - 3;
-            const unsigned long long addback = __ballot(gain_probe(thr7, thr50, en, nq, cand, target));
+            const unsigned long long addback = __ballot(gain_probe(thr7, thr50, en, nq, cand, offset0 - m - 3, target));
             if (addback & 1ull) { if (!(addback & 2ull)) m += 1; }
             else { m += 2; if (!(addback & 4ull)) m += 1; }
         }
@@ -1541,6 +1543,27 @@ STAGE void st_noise_factor(const lc3d_plan* __restrict__ P, WaveLds& L, int lane
     const bool split = CI(nbytes) <= 20 && dms == 100 && nz > 0;
     const int msplit = split ? sumz / nz : 0x7fffffff;
     float m1 = 0, m2 = 0; int j1 = 0;
+    if (!split) {
+        /* common case: one serial sum over all zero lines.  They are compacted (in bin order) into LDS scratch three chunks
+         * at a time and summed with uniform-address reads. */
+        float* lst = &L.sm[240];                    /* 308 free words: the residual-bit area is not in use yet */
+        j1 = nz;
+#pragma unroll
+        for (int g = 0; g < 8; g += 3) {
+            int cntg = 0;
+#pragma unroll
+            for (int c = g; c < g + 3 && c < 8; c++) {
+                const int k = first + 64 * c + lane;
+                const unsigned long long m = zm[c];
+                if ((m >> lane) & 1ull) lst[cntg + __popcll(m & ((1ull << lane) - 1ull))] = fabsf(L.A[k] / gg);
+                cntg += __popcll(m);
+            }
+            LSYNC();
+#pragma unroll 8
+            for (int j = 0; j < cntg; j++) m1 += lst[j];
+            LSYNC();
+        }
+    } else
 #pragma unroll
     for (int c = 0; c < 8; c++) {
         const int k = first + 64 * c + lane;
@@ -1773,19 +1796,28 @@ STAGE void st_bitstream(const lc3d_plan* __restrict__ P, const lc3d_chan* __rest
             or_bits_fwd(resb, nl + li - ln, lsbv, ln);
             nl += uni(__shfl(li, 63));
         }
-        /* serial part: wave-uniform */
-        const int cnt = imin(WAVE, ntup - c0);
-        for (int j = 0; j < cnt; j++) {
-            const int ml = __builtin_amdgcn_readlane(maxlev, j);
-            if (ml > 0) {
+        /* serial part: wave-uniform scalar code; runs of escape-free tuples take the short loop */
+        const int cnt = uni(imin(WAVE, ntup - c0));
+        const unsigned long long escm = __ballot(maxlev > 0);
+        int j = 0;
+        while (j < cnt) {
+            const unsigned long long rest = escm >> j;
+            const int e = imin(cnt, j + (rest ? (int)__ffsll((long long)rest) - 1 : 64));
+            for (; j < e; j++) {
+                const unsigned fv = (unsigned)__builtin_amdgcn_readlane((int)cfv, j);
+                ari_encode(w, bytes, lane, (int)(fv >> 16), (int)(fv & 0xffff));
+            }
+            if (j < cnt) {
+                const int ml = __builtin_amdgcn_readlane(maxlev, j);
                 for (int lev = 0; lev < ml; lev++) {
                     const unsigned ev = lev == 0 ? (unsigned)__builtin_amdgcn_readlane((int)e0, j) : lev == 1 ? (unsigned)__builtin_amdgcn_readlane((int)e1, j)
                                       : lev == 2 ? (unsigned)__builtin_amdgcn_readlane((int)e2, j) : (unsigned)__builtin_amdgcn_readlane((int)e3, j);
                     ari_encode(w, bytes, lane, (int)(ev >> 16), (int)(ev & 0xffff));
                 }
+                const unsigned fv = (unsigned)__builtin_amdgcn_readlane((int)cfv, j);
+                ari_encode(w, bytes, lane, (int)(fv >> 16), (int)(fv & 0xffff));
+                j++;
             }
-            const unsigned fv = (unsigned)__builtin_amdgcn_readlane((int)cfv, j);
-            ari_encode(w, bytes, lane, (int)(fv >> 16), (int)(fv & 0xffff));
         }
     }
     /* ---- residual / LSB bits (R/ari_codec.c:764-797) ---- */
