@@ -1104,22 +1104,22 @@ STAGE void st_sns_apply(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
 /* ------------------------------------------------------------------------------------------------ */
 /* TNS: R/tns_coder.c:170-362                                                                        */
 /* ------------------------------------------------------------------------------------------------ */
-struct TnsGeom { int numfilters, maxOrder, nSub, start[2], stop[2]; float maxPG; int obits_off; };
+struct TnsGeom { int numfilters, maxOrder, nSub, start0, start1, stop0, stop1; float maxPG; int obits_off; };   /* scalars only: no stack object */
 
 __device__ __forceinline__ TnsGeom tns_geom(WaveLds& L, int bw_idx, int bw_bin)
 {
     TnsGeom g;
     int fs = PI(fs), N = PI(N); const int nBits = CI(total_bits), dms = PI(dms);
     g.numfilters = (fs >= 32000 && dms >= 50) ? 2 : 1;
-    g.start[0] = g.start[1] = g.stop[0] = g.stop[1] = 0;
+    g.start0 = g.start1 = g.stop0 = g.stop1 = 0;
     if ((double)N > 40 * ((double)(float)dms / 10.0)) { N = (int)(40 * ((double)(float)dms / 10.0)); fs = 40000; }
-    g.start[0] = (600 * N * 2 / fs) + 1;
-    if (g.numfilters == 1) g.stop[0] = N; else { g.start[1] = N / 2 + 1; g.stop[0] = N / 2; g.stop[1] = N; }
+    g.start0 = (600 * N * 2 / fs) + 1;
+    if (g.numfilters == 1) g.stop0 = N; else { g.start1 = N / 2 + 1; g.stop0 = N / 2; g.stop1 = N; }
     g.maxOrder = dms == 100 ? 8 : 4; g.nSub = dms == 100 ? 3 : 2;
     g.maxPG = 2; g.obits_off = 8;
     if ((dms >= 50 && (double)nBits >= 48 * ((double)(float)dms / 10.0)) || dms == 25) { g.maxPG = 1.5f; g.obits_off = 0; }
-    if (bw_idx >= 3 && g.numfilters == 2) { g.start[1] = bw_bin / 2 + 1; g.stop[0] = bw_bin / 2; g.stop[1] = bw_bin; }
-    else { g.numfilters = 1; g.stop[0] = bw_bin; }
+    if (bw_idx >= 3 && g.numfilters == 2) { g.start1 = bw_bin / 2 + 1; g.stop0 = bw_bin / 2; g.stop1 = bw_bin; }
+    else { g.numfilters = 1; g.stop0 = bw_bin; }
     return g;
 }
 
@@ -1207,14 +1207,14 @@ STAGE int tns_analyze(const lc3d_plan* __restrict__ P, WaveLds& L, int lane, int
             for (int i = 0; i < 8; i++) rc[i] = i < maxOrder ? unif(L.sm[SM_MISC + 112 + 9 + i]) : 0.0f;
             LSYNC();
         }
+        {   /* R/tns_coder.c:157-168 findRC_idx: lane q tests its interval (thr[q], thr[q+1]] for every coefficient; the
+             * intervals are disjoint, so the ballot has at most one bit set (none -> 0, as in the reference) */
+            const float tlo = lc3t_tns_rc_thr[lane < 17 ? lane : 0], thi = lc3t_tns_rc_thr[lane < 17 ? lane + 1 : 1];
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            int ret = 0;
-            if (i < maxOrder) {
-#pragma unroll
-                for (int q = 0; q < 17; q++) if (rc[i] <= lc3t_tns_rc_thr[q + 1] && rc[i] > lc3t_tns_rc_thr[q]) ret = q;
+            for (int i = 0; i < 8; i++) {
+                const unsigned long long hit = __ballot(lane < 17 && rc[i] <= thi && rc[i] > tlo);
+                idxq[i] = (i < maxOrder && hit) ? 63 - __clzll((long long)hit) : 0;
             }
-            idxq[i] = ret;
         }
 #pragma unroll
         for (int i = 0; i < 8; i++) { const float q = i < maxOrder ? lc3t_tns_rc_pts[idxq[i]] : 0.0f; rc[i] = q; if (i < maxOrder && q != 0) ord = i + 1; }
@@ -1282,9 +1282,10 @@ STAGE void st_tns(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__
         if (lane < 54) { f = lane / 27; const int r = lane % 27; sub = r / 9; k = r % 9; }
         else { const int r = lane - 54; f = r / 3; sub = r % 3; }
         if (lane < 60 && f < G.numfilters && sub < G.nSub && (k <= G.maxOrder)) {
-            const float sublen = (float)(((double)(float)G.stop[f] + 1.0 - (double)(float)G.start[f]) / (double)(float)G.nSub);
-            const int lo = (int)(floor((double)(sublen * (float)sub)) + G.start[f] - 1);
-            const int hi = (int)(floor((double)(sublen * (float)(sub + 1))) + G.start[f] - 1);
+            const int fstart = f ? G.start1 : G.start0, fstop = f ? G.stop1 : G.stop0;
+            const float sublen = (float)(((double)(float)fstop + 1.0 - (double)(float)fstart) / (double)(float)G.nSub);
+            const int lo = (int)(floor((double)(sublen * (float)sub)) + fstart - 1);
+            const int hi = (int)(floor((double)(sublen * (float)(sub + 1))) + fstart - 1);
             const float* x = &L.A[lo]; const int n = hi - lo;
             float acc = 0;
             if (k < 0) {
@@ -1319,7 +1320,8 @@ STAGE void st_tns(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__
     for (int f = 0; f < G.numfilters; f++) {
         bits += tns_analyze(P, L, lane, f, G.maxOrder, G.maxPG, G.obits_off);
         const int ord = uni(L.isc[I_TNS_ORD0 + f]);
-        if (ord > 0) tns_lattice(L, lane, G.start[f] - 1, G.stop[f] - G.start[f] + 1, ord);
+        const int fstart = f ? G.start1 : G.start0, fstop = f ? G.stop1 : G.stop0;
+        if (ord > 0) tns_lattice(L, lane, fstart - 1, fstop - fstart + 1, ord);
     }
     if (lane == 0) { L.isc[I_TNS_NF] = G.numfilters; L.isc[I_TNS_BITS] = bits; }
     LSYNC();
@@ -1910,7 +1912,16 @@ lc3_encode_kernel(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__
         const size_t fidx = ((size_t)strm * T + t) * channels + ch;
         if (bitdepth == 16) {
             const int16_t* p = (const int16_t*)pcm + fidx * N;
-            for (int i = lane; i < N; i += WAVE) XCUR(L)[i] = (float)p[i];
+            if ((N & 7) == 0 && (((size_t)p) & 15) == 0) {          /* 16 B per lane: one wave-wide load for N <= 512 */
+                for (int i = lane; i < (N >> 3); i += WAVE) {
+                    const uint4 v = ((const uint4*)p)[i];
+                    float* d = &XCUR(L)[8 * i];
+                    d[0] = (float)(int16_t)(v.x & 0xffff); d[1] = (float)(int16_t)(v.x >> 16);
+                    d[2] = (float)(int16_t)(v.y & 0xffff); d[3] = (float)(int16_t)(v.y >> 16);
+                    d[4] = (float)(int16_t)(v.z & 0xffff); d[5] = (float)(int16_t)(v.z >> 16);
+                    d[6] = (float)(int16_t)(v.w & 0xffff); d[7] = (float)(int16_t)(v.w >> 16);
+                }
+            } else for (int i = lane; i < N; i += WAVE) XCUR(L)[i] = (float)p[i];
         } else {
             const int32_t* p = (const int32_t*)pcm + fidx * N;
             const float sc = bitdepth == 24 ? 256.0f : 65536.0f;
@@ -1997,7 +2008,9 @@ lc3_encode_kernel(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__
         if (tr && lane == 0) { tr->n_res_bits = L.isc[I_NRES]; tr->bp_side = L.isc[I_BP_SIDE]; tr->mask_side = L.isc[I_MASK_SIDE]; }
         /* ---- bytes out ---- */
         uint8_t* o = out + ((size_t)strm * T + t) * out_stride + CI(out_off);
-        for (int i = lane; i < CI(nbytes); i += WAVE) o[i] = BYTES(L)[i];
+        const int nby = CI(nbytes);
+        if (((nby | (int)(size_t)o) & 3) == 0) { for (int i = lane; i < (nby >> 2); i += WAVE) ((uint32_t*)o)[i] = ((const uint32_t*)BYTES(L))[i]; }
+        else for (int i = lane; i < nby; i += WAVE) o[i] = BYTES(L)[i];
         LSYNC();
         TICK(17);
     }
