@@ -701,7 +701,8 @@ STAGE void mdct_dft120(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)   
     }
     LSYNC();
 }
-STAGE void st_mdct(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
+/* window + fold + memory slide + pre-twiddle (leaf stage) */
+STAGE void mdct_pre(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
 {
     const int N = PI(N), h = N >> 1, la = PI(la), ml = N - la;
     const float* w = &lc3t_win_pool[PI(win_off)];
@@ -727,8 +728,11 @@ STAGE void st_mdct(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
         X[2 * i + 1] = ai * br + ar * bi;
     }
     LSYNC();
-    if (h == 240) { mdct_dft240_cols(L, lane); mdct_dft240_rows(L, lane); }
-    else mdct_dft120(P, L, lane);
+}
+/* post-twiddle (leaf stage) */
+STAGE void mdct_post(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
+{
+    const int N = PI(N), h = N >> 1;
     const float norm = PF(dct4_norm);
     float o0[4], o1[4];                              /* post-twiddle R/dct4.c:90-94, in place in A through registers (h <= 256) */
 #pragma unroll
@@ -1159,13 +1163,11 @@ STAGE void tns_lpc_weight(WaveLds& L, int lane, int maxOrder, float maxPG, float
     LSYNC();
 }
 
-/* Levinson-Durbin (R/tns_coder.c:41-89), prediction gain, reflection-coefficient quantisation and bit count for filter f.
- * Wave-uniform, fully unrolled for register residency.  Results: quantised rc -> sm[SM_MISC+104..], order / indices -> isc.
- * Returns the number of bits this filter adds (flag included). */
-STAGE int tns_analyze(const lc3d_plan* __restrict__ P, WaveLds& L, int lane, int f, int maxOrder, float maxPG, int obits_off)
+/* Levinson-Durbin (R/tns_coder.c:41-89) and prediction gain of filter f; wave-uniform, fully unrolled for register residency.
+ * Returns 0: filter off, 1: on, 2: on and LPC weighting required.  Leaves a[] at sc[36..], rc[] at sc[46..], predGain at sc[63]. */
+STAGE int tns_levinson(WaveLds& L, int lane, int f, int maxOrder, float maxPG)
 {
     const float* racc = &L.sm[SM_MISC];
-    float* rcs = &L.sm[SM_MISC + 104];
     float r[9], a[9], rc[8], buf[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) { r[i] = unif(racc[64 + f * 9 + i]); a[i] = 0; }
@@ -1190,23 +1192,31 @@ STAGE int tns_analyze(const lc3d_plan* __restrict__ P, WaveLds& L, int lane, int
         } else rc[t] = 0;
     }
     const float predGain = r[0] / v;
-    int tns = predGain > 1.5f;
+    const int tns = predGain > 1.5f;
+    if (lane == 0) {
+        float* sc = &L.sm[SM_MISC + 112];
+#pragma unroll
+        for (int j = 0; j < 9; j++) sc[36 + j] = a[j];
+#pragma unroll
+        for (int j = 0; j < 8; j++) sc[46 + j] = rc[j];
+        sc[63] = predGain;
+    }
+    LSYNC();
+    return tns ? (predGain < maxPG ? 2 : 1) : 0;
+}
+
+/* reflection-coefficient quantisation, order and bit count of filter f (R/tns_coder.c:289-336); `code` from tns_levinson.
+ * Results: quantised rc -> sm[SM_MISC+104..], order / indices -> isc.  Returns the bits this filter adds (flag included). */
+STAGE int tns_quant(WaveLds& L, int lane, int f, int maxOrder, int obits_off, int code)
+{
+    float* rcs = &L.sm[SM_MISC + 104];
+    const float* sc = &L.sm[SM_MISC + 112];
+    float rc[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) rc[i] = i < maxOrder ? unif(sc[(code == 2 ? 9 : 46) + i]) : 0.0f;
+    int tns = code != 0;
     int bits = 1, ord = 0; int idxq[8];
     if (tns) {
-        if (predGain < maxPG) {
-            if (lane == 0) {
-                float* sc = &L.sm[SM_MISC + 112];
-#pragma unroll
-                for (int j = 0; j < 9; j++) sc[36 + j] = a[j];
-#pragma unroll
-                for (int j = 0; j < 8; j++) sc[46 + j] = rc[j];
-            }
-            LSYNC();
-            tns_lpc_weight(L, lane, maxOrder, maxPG, predGain);
-#pragma unroll
-            for (int i = 0; i < 8; i++) rc[i] = i < maxOrder ? unif(L.sm[SM_MISC + 112 + 9 + i]) : 0.0f;
-            LSYNC();
-        }
         {   /* R/tns_coder.c:157-168 findRC_idx: lane q tests its interval (thr[q], thr[q+1]] for every coefficient; the
              * intervals are disjoint, so the ballot has at most one bit set (none -> 0, as in the reference) */
             const float tlo = lc3t_tns_rc_thr[lane < 17 ? lane : 0], thi = lc3t_tns_rc_thr[lane < 17 ? lane + 1 : 1];
@@ -1273,7 +1283,8 @@ STAGE void tns_lattice(WaveLds& L, int lane, int b_first, int cnt, int ord)
     LSYNC();
 }
 
-STAGE void st_tns(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ C, WaveLds& L, int lane, int bw_idx, int bw_bin)
+/* sub-division autocorrelations and the lag-windowed r[f][0..8] of both filters (R/tns_coder.c:258-281) */
+STAGE void tns_sums(WaveLds& L, int lane, int bw_idx, int bw_bin)
 {
     const TnsGeom G = tns_geom(L, bw_idx, bw_bin);
     float* racc = &L.sm[SM_MISC];              /* [f][sub][k] 2*3*9 = 54, sub-division energies 6 at +54, r[f][9] at +64 */
@@ -1316,9 +1327,19 @@ STAGE void st_tns(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__
     }
     if (lane >= 32 && lane < 40) L.sm[SM_MISC + 96 + lane - 32] = 0;     /* lattice state, persists from filter 0 to 1 */
     LSYNC();
+}
+
+/* TNS driver, inlined into the kernel so that the STAGE functions stay leaf calls (a nested call level makes the callee
+ * save registers to scratch, i.e. HBM write traffic that is not part of the algorithm) */
+__device__ __forceinline__ void st_tns(const lc3d_plan* __restrict__ P, WaveLds& L, int lane, int bw_idx, int bw_bin)
+{
+    tns_sums(L, lane, bw_idx, bw_bin);
+    const TnsGeom G = tns_geom(L, bw_idx, bw_bin);
     int bits = 0;
     for (int f = 0; f < G.numfilters; f++) {
-        bits += tns_analyze(P, L, lane, f, G.maxOrder, G.maxPG, G.obits_off);
+        const int code = tns_levinson(L, lane, f, G.maxOrder, G.maxPG);
+        if (code == 2) tns_lpc_weight(L, lane, G.maxOrder, G.maxPG, unif(L.sm[SM_MISC + 112 + 63]));
+        bits += tns_quant(L, lane, f, G.maxOrder, G.obits_off, code);
         const int ord = uni(L.isc[I_TNS_ORD0 + f]);
         const int fstart = f ? G.start1 : G.start0, fstop = f ? G.stop1 : G.stop0;
         if (ord > 0) tns_lattice(L, lane, fstart - 1, fstop - fstart + 1, ord);
@@ -1939,7 +1960,9 @@ lc3_encode_kernel(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__
         TICK(4);
         if (CI(attack_handling)) st_attack(P, L, lane);
         TICK(5);
-        st_mdct(P, L, lane);
+        mdct_pre(P, L, lane);
+        if (PI(N) == 480) { mdct_dft240_cols(L, lane); mdct_dft240_rows(L, lane); } else mdct_dft120(P, L, lane);
+        mdct_post(P, L, lane);
         TICK(1);
         if (tr) for (int i = lane; i < N; i += WAVE) tr->spec_mdct[i] = L.A[i];
         st_energy_bw(P, L, lane);
@@ -1971,7 +1994,7 @@ lc3_encode_kernel(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__
         if (lane < 16) L.isc[I_TNS_IDX0 + lane] = 0;
         if (lane < 2) L.isc[I_TNS_ORD0 + lane] = 0;
         LSYNC();
-        st_tns(P, C, L, lane, bw, bw_bin);
+        st_tns(P, L, lane, bw, bw_bin);
         TICK(10);
         const int tns_bits = uni(L.isc[I_TNS_BITS]);
         if (tr) { if (lane == 0) { tr->bw_idx = bw; tr->tns_nfilt = L.isc[I_TNS_NF]; tr->tns_order[0] = L.isc[I_TNS_ORD0]; tr->tns_order[1] = L.isc[I_TNS_ORD1]; tr->tns_bits = tns_bits; }

@@ -20,6 +20,14 @@ sys.path.insert(0, ROOT)
 
 FS, FRAME_MS, N, BITRATE, NBYTES = 48000, 10.0, 480, 64000, 80
 ALGO_BYTES_PER_FRAME = 2 * N + NBYTES          # int16 PCM in + bitstream out = 1040
+# The other BASELINE.json configs (parity-test cases; selectable for the record with --workload, never the default):
+#   name: (fs, frame_ms, hrmode, channels, N, per-stream total bitrates (cycled), frames per step)
+WORKLOADS = {
+    "c1": (48000, 10.0, 0, 1, 480, [64000], 64),
+    "c3": (48000, 10.0, 0, 2, 480, [128000], 16),
+    "c4": (96000, 2.5, 1, 1, 240, [256000], 256),
+    "c5": (48000, 10.0, 0, 1, 480, [16000, 24000, 32000, 48000, 64000, 80000, 96000, 128000, 160000, 192000, 256000, 320000], 64),
+}
 HBM_PEAK_GBS = 8000.0                          # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
@@ -84,6 +92,53 @@ def _cpu_worker(args):
     return time.time() - t0
 
 
+def other_workload(a):
+    """Single-GPU record runs of the other BASELINE configs (same timing protocol; no CPU baseline; informational)."""
+    import torch
+    import audio_codec_amd
+    fs, ms, hr, ch, n, rates, T = WORKLOADS[a.workload]
+    if a.frames != 64: T = a.frames
+    B = a.streams
+    dev = torch.device("cuda", 0); torch.cuda.set_device(0)
+    g = torch.Generator(device=dev); g.manual_seed(99)
+    pcm = (torch.randn(B, T, ch, n, device=dev, generator=g) * 3000).round().clamp(-32768, 32767).to(torch.int16)
+    pcm += (8000 * torch.sin(torch.arange(n, device=dev) * 0.05)).to(torch.int16)[None, None, None, :]
+    br = [rates[i % len(rates)] for i in range(B)]
+    batch = audio_codec_amd.Batch(B, fs, ch, ms, hr, br, device=0)
+    stride = batch.stride
+    out = torch.zeros(B, T, stride, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    for _ in range(a.warmup): batch.encode_device(pcm.data_ptr(), 16, T, out.data_ptr(), stride, hip_stream=stream.cuda_stream)
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter(); e0.record(stream)
+    for _ in range(a.steps): batch.encode_device(pcm.data_ptr(), 16, T, out.data_ptr(), stride, hip_stream=stream.cuda_stream)
+    e1.record(stream); torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    nbytes = [batch.num_bytes(i) for i in range(min(B, len(rates)))]
+    algo = B * T * (2 * n * ch) + T * sum(batch.num_bytes(i) for i in range(B))
+    kern_ms = e0.elapsed_time(e1) / a.steps
+    print(json.dumps({"metric": "Mframes/s encoded (channel-frames)", "value": round(B * T * ch * a.steps / wall / 1e6, 4), "unit": "Mframes/s",
+                      "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(wall / a.steps * 1e3, 4), "higher_is_better": True,
+                      "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                      "config": {"workload": "%s: %d streams x %d frames, %d Hz / %.1f ms%s, %d ch, bytes/frame %s" % (a.workload, B, T, fs, ms, " hr" if hr else "", ch, nbytes)},
+                      "roofline": {"bound": "hbm", "achieved": round(algo / (kern_ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": round(algo / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None, "kernel_ms_avg": round(kern_ms, 4)}}))
+
+
+def measured_traffic(workload, B, T):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_traffic.json);
+    only valid for the launch shape it was collected on, otherwise null."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            t = json.load(f)
+        if t["workload"] == workload and t["streams"] == B and t["frames"] == T:
+            return int(t["traffic_bytes"])
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -92,7 +147,10 @@ def main():
     ap.add_argument("--streams", type=int, default=4096, help="independent mono streams per GPU (BASELINE configs[1])")
     ap.add_argument("--frames", type=int, default=64, help="frames per stream per step (SURVEY 8(d): T = 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="c1", choices=sorted(WORKLOADS), help="c1 = BASELINE configs[1] (the metric's configuration)")
     a = ap.parse_args()
+    if a.workload != "c1":
+        return other_workload(a)
 
     import torch
     import audio_codec_amd
@@ -155,7 +213,7 @@ def main():
                                    "48kHz/10ms/64kbps, one channel-stream per wavefront" % (B, T),
                        "streams_per_gpu": B, "frames_per_step": T, "parallelism": "streams sharded over %d GPU(s), no collectives" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": measured_traffic(a.workload, B, T),
                          "kernel": "lc3_encode_kernel", "kernel_ms_avg": round(kern_ms, 4),
                          "algorithmic_bytes_per_launch": B * T * ALGO_BYTES_PER_FRAME,
                          "note": "serial-chain (instruction-issue) bound, not HBM bound: see DESIGN.md"},
