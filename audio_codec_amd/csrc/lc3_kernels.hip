@@ -38,10 +38,14 @@
 /* Diagnostic build only (-DLC3_STAGE_TIMING, tools/stage_timing.py): per-stage wave-latency accounting with s_memtime.
  * The product library is built without it; no stamp executes there. */
 #ifdef LC3_STAGE_TIMING
-#define NSTAGE 24
+#define NSTAGE 64                       /* 0..23: stages, 24..63: sub-stage stamps */
 #define TICK(id) do { long long now_ = clock64(); if (lane == 0) L.tacc[id] += now_ - tlast; tlast = now_; } while (0)
+#define SUB_BEGIN() long long ts_ = clock64()
+#define SUB(id) do { long long n_ = clock64(); if (lane == 0) L.tacc[24 + (id)] += n_ - ts_; ts_ = n_; } while (0)
 #else
 #define TICK(id) do { } while (0)
+#define SUB_BEGIN() do { } while (0)
+#define SUB(id) do { } while (0)
 #endif
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -116,29 +120,59 @@ __device__ __forceinline__ int flog2f_int(unsigned v)
     return e;
 }
 
-__device__ __forceinline__ float wave_max_f(float v) { for (int o = 32; o; o >>= 1) v = fmaxf(v, __shfl_xor(v, o)); return v; }
-__device__ __forceinline__ int wave_max_i(int v) { for (int o = 32; o; o >>= 1) v = imax(v, __shfl_xor(v, o)); return v; }
-__device__ __forceinline__ int wave_sum_i(int v) { for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o); return v; }
+/* Cross-lane primitives on DPP (row_shr 1/2/4/8 inside a row of 16, row_bcast:15 / :31 across rows): ~6 dependent VALU ops per
+ * wave-wide scan or reduction instead of six LDS-crossbar round trips (ds_bpermute, ~60 cycles each).  A lane without a source
+ * keeps `old`. */
+template <int CTRL, int RM = 0xF> __device__ __forceinline__ int dpp_i(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, RM, 0xF, false); }
+template <int CTRL, int RM = 0xF> __device__ __forceinline__ float dpp_f(float old, float v)
+{ return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, RM, 0xF, false)); }
+#define DPP_SHR1 0x111
+#define DPP_SHR2 0x112
+#define DPP_SHR4 0x114
+#define DPP_SHR8 0x118
+#define DPP_BC15 0x142
+#define DPP_BC31 0x143
 __device__ __forceinline__ int wave_incl_scan_i(int v, int lane)
 {
-    for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(v, o); if (lane >= o) v += t; }
+    (void)lane;
+    v += dpp_i<DPP_SHR1>(0, v); v += dpp_i<DPP_SHR2>(0, v); v += dpp_i<DPP_SHR4>(0, v); v += dpp_i<DPP_SHR8>(0, v);
+    v += dpp_i<DPP_BC15, 0xA>(0, v); v += dpp_i<DPP_BC31, 0xC>(0, v);
     return v;
 }
-/* first index of the maximum (strict '>' scan order): ties resolve to the lowest index */
-__device__ __forceinline__ void wave_argmax_first(float& v, int& i, int width)
+/* reductions return the wave-uniform result (lane 63 of the scan) */
+__device__ __forceinline__ int wave_sum_i(int v) { return __builtin_amdgcn_readlane(wave_incl_scan_i(v, 0), 63); }
+__device__ __forceinline__ float wave_max_f(float v)
 {
-    for (int o = width >> 1; o; o >>= 1) {
-        float ov = __shfl_xor(v, o); int oi = __shfl_xor(i, o);
-        if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
-    }
+    v = fmaxf(v, dpp_f<DPP_SHR1>(v, v)); v = fmaxf(v, dpp_f<DPP_SHR2>(v, v)); v = fmaxf(v, dpp_f<DPP_SHR4>(v, v)); v = fmaxf(v, dpp_f<DPP_SHR8>(v, v));
+    v = fmaxf(v, dpp_f<DPP_BC15, 0xA>(v, v)); v = fmaxf(v, dpp_f<DPP_BC31, 0xC>(v, v));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
-__device__ __forceinline__ void wave_argmin_first(float& v, int& i, int width)
+__device__ __forceinline__ int wave_max_i(int v)
 {
-    for (int o = width >> 1; o; o >>= 1) {
-        float ov = __shfl_xor(v, o); int oi = __shfl_xor(i, o);
-        if (ov < v || (ov == v && oi < i)) { v = ov; i = oi; }
-    }
+    v = imax(v, dpp_i<DPP_SHR1>(v, v)); v = imax(v, dpp_i<DPP_SHR2>(v, v)); v = imax(v, dpp_i<DPP_SHR4>(v, v)); v = imax(v, dpp_i<DPP_SHR8>(v, v));
+    v = imax(v, dpp_i<DPP_BC15, 0xA>(v, v)); v = imax(v, dpp_i<DPP_BC31, 0xC>(v, v));
+    return __builtin_amdgcn_readlane(v, 63);
 }
+/* first index of the maximum / minimum (scan order with strict compare): ties resolve to the lowest index.  WIDTH 64: one result,
+ * returned uniform in (v, i).  WIDTH 16 / 32: the result of group 0 is returned uniform (lane 15 / 31); ARG32B additionally hands
+ * back the second 32-lane group's index. */
+#define ARG_STEP(CTRL, RM, CMP) do { const float ov = dpp_f<CTRL, RM>(v, v); const int oi = dpp_i<CTRL, RM>(i, i); \
+        const bool t = (ov CMP v) || (ov == v && oi < i); v = t ? ov : v; i = t ? oi : i; } while (0)
+template <int WIDTH> __device__ __forceinline__ void wave_argmax_first(float& v, int& i)
+{
+    ARG_STEP(DPP_SHR1, 0xF, >); ARG_STEP(DPP_SHR2, 0xF, >); ARG_STEP(DPP_SHR4, 0xF, >); ARG_STEP(DPP_SHR8, 0xF, >);
+    if (WIDTH >= 32) ARG_STEP(DPP_BC15, 0xA, >);
+    if (WIDTH >= 64) ARG_STEP(DPP_BC31, 0xC, >);
+    v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), WIDTH - 1)); i = __builtin_amdgcn_readlane(i, WIDTH - 1);
+}
+/* two independent 32-lane argmin searches (lanes 0-31 and 32-63); returns both winning indices, uniform */
+__device__ __forceinline__ void wave_argmin_first_2x32(float v, int i, int& i_lo, int& i_hi)
+{
+    ARG_STEP(DPP_SHR1, 0xF, <); ARG_STEP(DPP_SHR2, 0xF, <); ARG_STEP(DPP_SHR4, 0xF, <); ARG_STEP(DPP_SHR8, 0xF, <);
+    ARG_STEP(DPP_BC15, 0xA, <);
+    i_lo = __builtin_amdgcn_readlane(i, 31); i_hi = __builtin_amdgcn_readlane(i, 63);
+}
+#undef ARG_STEP
 
 /* ------------------------------------------------------------------------------------------------ */
 /* DFT kernels (register resident).  Exact operand order of R/fft/fft_15_16.h and R/fft/fft_2_9.h.   */
@@ -304,6 +338,7 @@ STAGE void st_resample(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
     const float sf = PF(rs_scale);
     const float* buf = &L.xbuf[MEMCAP - mlen];      /* [mem_in | x] */
     float d[2] = {0, 0};
+    SUB_BEGIN();
 #pragma unroll
     for (int h = 0; h < 2; h++) {                   /* one polyphase FIR output per lane and half: taps in the reference's order */
         const int n = lane + 64 * h;
@@ -319,6 +354,7 @@ STAGE void st_resample(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
     }
     /* biquad in double, strictly serial (R/resamp12k8.c:60-74): the x-only products b_k*x are formed per lane and parked in LDS
      * (A and sm are idle here), the recurrence streams them back with uniform-address reads (LDS issue, not VALU issue) */
+    SUB(0);
     const double b0 = lc3t_hp50_b[0], b1 = lc3t_hp50_b[1], b2 = lc3t_hp50_b[2], a1 = lc3t_hp50_a[1], a2 = lc3t_hp50_a[2];
     double* q0 = (double*)L.A; double* q1 = (double*)L.sm; double* q2 = q1 + 128;
 #pragma unroll
@@ -329,6 +365,7 @@ STAGE void st_resample(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
     LSYNC();
     double u11 = (double)L.fsc[F_HP0], u21 = (double)L.fsc[F_HP1];
     float y[2] = {0, 0};
+    SUB(1);
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         const int cnt = imin(len12 - 64 * h, 64);
@@ -341,6 +378,7 @@ STAGE void st_resample(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
             y[h] = (lane == i) ? (float)y1 : y[h];
         }
     }
+    SUB(2);
     float keep[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) { const int i = lane + 64 * k; keep[k] = (i + len12 < 384) ? L.h12[i + len12] : 0.0f; }
@@ -351,6 +389,7 @@ STAGE void st_resample(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
     if (lane + 64 < len12) L.h12[384 - len12 + 64 + lane] = y[1];
     if (lane == 0) { L.fsc[F_HP0] = (float)u11; L.fsc[F_HP1] = (float)u21; }
     LSYNC();
+    SUB(3);
 }
 
 /* normalised correlation at lag T over acf <= 64 samples (R/olpa.c:104-114): the three serial float sums run in all lanes,
@@ -404,14 +443,14 @@ STAGE void st_olpa(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
     if (two) R0[64 + lane] = r1;
     float best = r0 * lc3t_olpa_w[lane]; int besti = lane;
     if (two) { const float w1 = r1 * lc3t_olpa_w[64 + lane]; if (w1 > best) { best = w1; besti = 64 + lane; } }
-    wave_argmax_first(best, besti, 64);
+    wave_argmax_first<64>(best, besti);
     int T0 = uni(besti) + 17;
     LSYNC();
     float nc = olpa_normcorr(L, s6, acf, T0, lane, PF(c_1em5_a));
     const int old = uni(L.isc[I_OLPA_PITCH]);
     const int lo = imax(17, old - 4), hi = imin(114, old + 4), cnt = hi - lo + 1;
     float v = (lane & 15) < cnt ? R0[lo - 17 + (lane & 15)] : -INFINITY; int vi = lane & 15;
-    wave_argmax_first(v, vi, 16);
+    wave_argmax_first<16>(v, vi);
     const int T02 = uni(vi) + lo;
     if (T02 != T0) {
         const float nc2 = olpa_normcorr(L, s6, acf, T02, lane, PF(c_1em5_a));
@@ -466,7 +505,7 @@ STAGE void st_ltpf(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict_
         }
         LSYNC();
         int tsel;
-        { float v = lane < 16 && lane < t_max - t_min - 8 + 1 ? cor[4 + lane] : -INFINITY; int vi = lane & 15; wave_argmax_first(v, vi, 16);
+        { float v = lane < 16 && lane < t_max - t_min - 8 + 1 ? cor[4 + lane] : -INFINITY; int vi = lane & 15; wave_argmax_first<16>(v, vi);
           tsel = unif(v) > 0 ? uni(vi) : 0; }
         const int t1 = tsel + t0_min;
         int pitch_int, pitch_fr;
@@ -487,7 +526,7 @@ STAGE void st_ltpf(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict_
             const int mid = 4 * (t1 - t0_min) + 1, up = 4 - step, down = t1 == t0_min ? 0 : 4 - step;
             const int cnt = ((mid + up) - (mid - down)) / step + 1;
             int ksel;
-            { float v = (lane & 15) < cnt ? cor_int[mid - down - 1 + (lane & 15) * step] : -INFINITY; int vi = lane & 15; wave_argmax_first(v, vi, 16);
+            { float v = (lane & 15) < cnt ? cor_int[mid - down - 1 + (lane & 15) * step] : -INFINITY; int vi = lane & 15; wave_argmax_first<16>(v, vi);
               ksel = unif(v) > 0 ? uni(vi) : 0; }
             pitch_fr = ksel * step - down;
             if (pitch_fr >= 0) pitch_int = t1; else { pitch_int = t1 - 1; pitch_fr = 4 + pitch_fr; }
@@ -869,41 +908,44 @@ STAGE void st_sns_scf(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
 }
 
 /* ---- PVQ pulse search R/sns_quantize_scf.c:43-136: one search per lane, everything in registers ---- */
+/* PVQ pulse search R/sns_quantize_scf.c:43-136, one lane per search, state in registers.  Written branch-free: dimensions beyond
+ * `dim` carry |x| = 0 (adding +0 is exact, so the serial sums need no guard) and are masked out of the candidate scan; every
+ * decision is a select, because a divergent branch costs more than the whole 16-candidate chain step it would skip. */
 __device__ __forceinline__ void pvq_search_reg(WaveLds& L, const float* x_in, int dim, int pulses, int* y_out, float* yn_out)
 {
     float xabs[16]; int y[16];
-    float xsum = 0, yy = 0, xy = 0;
+    float xsum = 0, yy = 0, xy = 0; unsigned negm = 0;
 #pragma unroll
-    for (int i = 0; i < 16; i++) { xabs[i] = i < dim ? fabsf(x_in[i]) : 0.0f; y[i] = 0; }
+    for (int i = 0; i < 16; i++) { const float xv = x_in[i]; xabs[i] = i < dim ? fabsf(xv) : 0.0f; negm |= (xv >= 0 ? 0u : 1u) << i; y[i] = 0; }
 #pragma unroll
-    for (int i = 0; i < 16; i++) if (i < dim) xsum += xabs[i];
-    if (xsum > PF(c_2m24)) {
-        int tot = 0;
-        const float proj = (float)(pulses - 1) / xsum;
+    for (int i = 0; i < 16; i++) xsum += xabs[i];
+    const bool live = xsum > PF(c_2m24);
+    int tot = live ? 0 : pulses;
+    const float proj = live ? (float)(pulses - 1) / xsum : 0.0f;
 #pragma unroll
-        for (int i = 0; i < 16; i++) if (i < dim) {
-            const int yi = (int)floorf(xabs[i] * proj);
-            y[i] = yi; tot += yi;
-            yy = yy + (float)(yi * yi);
-            xy = xy + xabs[i] * (float)yi;
+    for (int i = 0; i < 16; i++) {
+        const int yi = (int)floorf(xabs[i] * proj);
+        y[i] = yi; tot += yi;
+        yy = yy + (float)(yi * yi);
+        xy = xy + xabs[i] * (float)yi;
+    }
+    yy = yy * 0.5f;
+    while (tot < pulses) {
+        int imx = 0; float cnum = -PF(c_2p15), cden = 0, xs = 0; int ys = 0;
+        yy = yy + 0.5f;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            float a = xy + xabs[i]; a = a * a;
+            const float b = yy + (float)y[i];
+            const bool t = (i < dim) & (a * cden > b * cnum);
+            cnum = t ? a : cnum; cden = t ? b : cden; imx = t ? i : imx; xs = t ? xabs[i] : xs; ys = t ? y[i] : ys;
         }
-        yy = yy * 0.5f;
-        while (tot < pulses) {
-            int imx = 0; float cnum = -PF(c_2p15), cden = 0;
-            yy = yy + 0.5f;
 #pragma unroll
-            for (int i = 0; i < 16; i++) if (i < dim) {
-                float a = xy + xabs[i]; a = a * a;
-                const float b = yy + (float)y[i];
-                if (a * cden > b * cnum) { cnum = a; cden = b; imx = i; }
-            }
-            float xs = 0; int ys = 0;
-#pragma unroll
-            for (int i = 0; i < 16; i++) if (i == imx) { xs = xabs[i]; ys = y[i]; y[i] = ys + 1; }
-            xy = xy + xs; yy = yy + (float)ys; tot++;
-        }
-        yy = yy * 2.0f;
-    } else {
+        for (int i = 0; i < 16; i++) y[i] += (i == imx) ? 1 : 0;
+        xy = xy + xs; yy = yy + (float)ys; tot++;
+    }
+    yy = yy * 2.0f;
+    if (!live) {
         /* all-zero target: the reference puts the pulses at y[0] and (out of range) y[dim]; only y[0] is ever read back */
         const int y0 = pulses / 2, yd = -(pulses - pulses / 2);
         y[0] = y0;
@@ -912,24 +954,39 @@ __device__ __forceinline__ void pvq_search_reg(WaveLds& L, const float* x_in, in
     const float g = (float)(1.0 / (double)sqrtf(yy));
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-        int yi = 0;
-        if (i < dim) { yi = x_in[i] >= 0 ? y[i] : -y[i]; }
-        y_out[i] = yi; yn_out[i] = i < dim ? (float)yi * g : 0.0f;
+        const int yi = ((negm >> i) & 1u) ? -y[i] : y[i];      /* y[i] is 0 beyond dim */
+        y_out[i] = yi; yn_out[i] = (float)yi * g;
     }
 }
 
-/* MPVQ enumeration R/sns_quantize_scf.c:138-163 (integer) over pulses held in LDS */
-__device__ void mpvq_index(const int* pulses, int len, int& ls, int& idx)
+/* MPVQ enumeration R/sns_quantize_scf.c:138-163 (integer), lane-parallel.  The reference walks pos = len-1 .. 0 with
+ *   if (ls >= 0 && pv != 0) idx = 2*idx + ls;  ls = sign(pv) if pv != 0;  idx += offs[(len-pos-1)*11 + k];  k += |pv|
+ * i.e. an affine map idx -> m*idx + c per step with m in {1, 2}.  Lane n of a 16-lane row takes step n: k is an exclusive
+ * prefix sum, the sign in force is that of the nearest earlier non-zero, and idx = sum_n c_n << (doublings after n).
+ * Row 0 enumerates pulses[0..len0), row 1 pulses[10..16) (the 6-dimensional part of the split shape); results are uniform. */
+__device__ __forceinline__ void mpvq_index_rows(const int* pulses, int lane, int len0, int& ls0, int& idx0, int& ls1, int& idx1)
 {
-    int k = 0; ls = -1; idx = 0;
-    for (int pos = len - 1; pos >= 0; pos--) {
-        const int pv = pulses[pos];
-        if (ls >= 0 && pv != 0) idx = 2 * idx + ls;
-        if (pv > 0) ls = 0;
-        if (pv < 0) ls = 1;
-        idx = idx + (int)lc3t_mpvq_offs[(len - pos - 1) * 11 + k];
-        k += pv < 0 ? -pv : pv;
-    }
+    const int grp = lane >> 4, n = lane & 15;
+    const int len = grp == 0 ? len0 : 6;
+    const bool on = lane < 32 && n < len;
+    const int pv = on ? pulses[(grp ? 10 : 0) + len - 1 - n] : 0;
+    const int sh = 16 * grp;
+    const unsigned nzm = (unsigned)(__ballot(pv != 0) >> sh) & 0xFFFFu, ngm = (unsigned)(__ballot(pv < 0) >> sh) & 0xFFFFu;
+    const unsigned below = nzm & ((1u << n) - 1u);
+    const int ls_prev = below ? (int)((ngm >> (31 - __clz((int)below))) & 1u) : -1;
+    const int apv = pv < 0 ? -pv : pv;
+    int k = apv;                                      /* inclusive prefix sum inside the row */
+    k += dpp_i<DPP_SHR1>(0, k); k += dpp_i<DPP_SHR2>(0, k); k += dpp_i<DPP_SHR4>(0, k); k += dpp_i<DPP_SHR8>(0, k);
+    k -= apv;
+    const unsigned off = on ? lc3t_mpvq_offs[n * 11 + k] : 0u;
+    const bool dbl = below != 0 && pv != 0;
+    const unsigned dbm = (unsigned)(__ballot(dbl) >> sh) & 0xFFFFu;
+    const int d = __popc(dbm >> (n + 1));
+    int c = (int)((off + (dbl ? (unsigned)ls_prev : 0u)) << d);
+    c += dpp_i<DPP_SHR1>(0, c); c += dpp_i<DPP_SHR2>(0, c); c += dpp_i<DPP_SHR4>(0, c); c += dpp_i<DPP_SHR8>(0, c);
+    const int lsf = nzm ? (int)((ngm >> (31 - __clz((int)nzm))) & 1u) : -1;
+    idx0 = __builtin_amdgcn_readlane(c, 15); idx1 = __builtin_amdgcn_readlane(c, 31);
+    ls0 = __builtin_amdgcn_readlane(lsf, 0); ls1 = __builtin_amdgcn_readlane(lsf, 16);
 }
 
 /* ---- SNS vector quantiser R/sns_quantize_scf.c:165-430 (+ DCT-II(16) R/dct4.c:28-48, IDCT-II :19-41) ---- */
@@ -939,30 +996,36 @@ STAGE void st_sns_vq(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
     float* st1 = &L.sm[SM_ST1]; float* tgt = &L.sm[SM_TGT]; float* tgtp = &L.sm[SM_TGTP];
     float* vec = &L.sm[SM_VEC];
     int* isc = L.isc;
+    SUB_BEGIN();
     {   /* stage 1: lane = sec*32 + codeword */
         const int sec = lane >> 5, c = lane & 31;
         const float* cb = sec ? lc3t_sns_hf : lc3t_sns_lf;
         float sum = 0;
 #pragma unroll
         for (int i = 0; i < 8; i++) { const float d = env[8 * sec + i] - cb[c * 8 + i]; sum += d * d; }
-        int bi = c;
-        wave_argmin_first(sum, bi, 32);
+        int bi0, bi1;
+        wave_argmin_first_2x32(sum, c, bi0, bi1);
+        const int bi = sec ? bi1 : bi0;
         if (c == 0) isc[I_SCF0 + sec] = bi;
         if (c < 8) { const float s = cb[bi * 8 + c]; st1[8 * sec + c] = s; tgtp[8 * sec + c] = env[8 * sec + c] - s; }
     }
     LSYNC();
+    SUB(4);
     {   /* DCT-II(16): every lane runs the 16-point DFT on the same data, lanes < 16 keep one output */
         float z[32];
 #pragma unroll
         for (int i = 0; i < 8; i++) { z[2 * i] = tgtp[2 * i]; z[2 * i + 1] = 0; z[2 * (15 - i)] = tgtp[2 * i + 1]; z[2 * (15 - i) + 1] = 0; }
         dft16(z);
-        float o = 0;
+        float zr = 0, zi = 0;
 #pragma unroll
-        for (int i = 0; i < 16; i++) if (lane == i) o = z[2 * i] * P->dct2_tw[2 * i] - z[2 * i + 1] * P->dct2_tw[2 * i + 1];
+        for (int i = 0; i < 16; i++) { zr = (lane == i) ? z[2 * i] : zr; zi = (lane == i) ? z[2 * i + 1] : zi; }
+        const float twr = P->dct2_tw[2 * (lane & 15)], twi = P->dct2_tw[2 * (lane & 15) + 1];
+        float o = zr * twr - zi * twi;
         if (lane == 0) o = o / PF(c_sqrt2);
         if (lane < 16) tgt[lane] = o;
     }
     LSYNC();
+    SUB(5);
     /* four pulse searches, one lane each: 0:(N=10,K=10) 1:(N=6,K=1 on tgt+10) 2:(N=16,K=8) 3:(N=16,K=6) */
     float* pv = &L.sm[SM_PVQ];
     if (lane < 4) {
@@ -970,6 +1033,7 @@ STAGE void st_sns_vq(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
         pvq_search_reg(L, lane == 1 ? tgt + 10 : tgt, dim, K, (int*)(pv + lane * 32), pv + lane * 32 + 16);
     }
     LSYNC();
+    SUB(6);
     const int* pA = (const int*)(pv); const int* pB = (const int*)(pv + 32);
     const int* pN = (const int*)(pv + 64); const int* pF = (const int*)(pv + 96);
     const float* nA = pv + 16; const float* nN = pv + 64 + 16; const float* nF = pv + 96 + 16;
@@ -1013,6 +1077,7 @@ STAGE void st_sns_vq(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
         idc[48 + lane] = PF(c_idct_n1) * sum;
     }
     LSYNC();
+    SUB(7);
     const float* split = &idc[48]; const float* subN = &idc[64]; const float* subF = &idc[80];
     /* error of the split candidate and of the 4 near / 8 far gains: one serial 16-term sum per lane (0 split, 1-4 near, 5-12 far) */
     float err = INFINITY;
@@ -1049,16 +1114,15 @@ STAGE void st_sns_vq(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
         ((int*)vec)[lane] = pl;
     }
     LSYNC();
-    if (lane == 0) {
-        const int* pulses = (const int*)vec;
-        int ls, mi;
-        if (sub_mode < 2) mpvq_index(pulses, 10, ls, mi); else mpvq_index(pulses, 16, ls, mi);
-        int i6;
-        if (sub_mode == 0) { int a, b; mpvq_index(pulses + 10, 6, a, b); i6 = b * 2 + a; }
-        else if (sub_mode == 2) i6 = -1; else i6 = -2;
-        isc[I_SCF2] = sub_mode; isc[I_SCF3] = sub_gain; isc[I_SCF4] = ls; isc[I_SCF5] = mi; isc[I_SCF6] = i6;
+    SUB(8);
+    {
+        int ls, mi, a6, b6;
+        mpvq_index_rows((const int*)vec, lane, sub_mode < 2 ? 10 : 16, ls, mi, a6, b6);
+        const int i6 = sub_mode == 0 ? b6 * 2 + a6 : sub_mode == 2 ? -1 : -2;
+        if (lane == 0) { isc[I_SCF2] = sub_mode; isc[I_SCF3] = sub_gain; isc[I_SCF4] = ls; isc[I_SCF5] = mi; isc[I_SCF6] = i6; }
     }
     LSYNC();
+    SUB(9);
 }
 
 /* ---- SNS interpolation R/sns_interpolate_scf.c:13-89 and spectral shaping R/mdct_shaping.c:13-22 ---- */
@@ -1354,25 +1418,45 @@ __device__ __forceinline__ void st_tns(const lc3d_plan* __restrict__ P, WaveLds&
 
 /* one bisection probe of R/estimate_global_gain.c:97-124 for this lane's candidate offset; the energies come from
  * lane registers (e0: j < 64, e1: j >= 64) through readlane, so the 100-step serial chain never touches LDS */
-__device__ __forceinline__ bool gain_probe(float thr7, float thr50, const float* en, int nq, int cand, int cand_min, float target)
+/* keep a value opaque to the optimiser: stops it from sinking the (double) arithmetic of a select operand into a divergent
+ * branch (a taken branch costs ~30 cycles on this chain, a v_cndmask 8) */
+__device__ __forceinline__ float opaque(float v) { asm volatile("" : "+v"(v)); return v; }
+__device__ __forceinline__ double opaque_d(double v) { asm volatile("" : "+v"(v)); return v; }
+
+/* number of leading (low-j) energies a probe has to visit: while even the smallest candidate of the wave sees
+ * en[j] - cand < thr7 and no lane has left the all-zero state, a step is a no-op, so the trailing run of such j is skipped */
+__device__ __forceinline__ int gain_probe_len(float thr7, float e0, float e1, int lane, int nq, int cand_min)
 {
-    float ener = 0; int iszero = 1;
-    const float fc = (float)cand, fmin = (float)cand_min;
-    /* while even the smallest candidate sees en[j] - cand < thr7 and no lane has left the all-zero state, a step is a no-op */
-    while (nq > 0 && en[nq - 1] - fmin < thr7) nq--;
-#define GSTEP(ev) do { const float t = (ev) - fc; const bool lo = t < thr7, hi = t > thr50; \
-        const float e_c = (float)((double)ener + (2.7) * (28.0 / 20.0)), e_b = (float)((double)ener + 2.0 * (double)t - (50.0) * (28.0 / 20.0)), e_a = ener + t; \
-        ener = lo ? (iszero ? ener : e_c) : (hi ? e_b : e_a); iszero = lo ? iszero : 0; } while (0)
-#pragma unroll 4
-    for (int j = nq - 1; j >= 0; j--) GSTEP(en[j]);
+    const float fmin = (float)cand_min;
+    const unsigned long long m0 = __ballot(lane < nq && !(e0 - fmin < thr7)), m1 = __ballot(lane + 64 < nq && !(e1 - fmin < thr7));
+    return uni(m1 ? 128 - (int)__clzll((long long)m1) : m0 ? 64 - (int)__clzll((long long)m0) : 0);
+}
+
+__device__ __forceinline__ bool gain_probe(float thr7, float thr50, const float* en, int nq, int cand, float target)
+{
+    float ener = 0; bool iszero = true;
+    const float fc = (float)cand;
+    /* one step of R/estimate_global_gain.c:103-121, branch-free.  All four outcomes have the form (float)(((double)ener + X) + Y):
+     * unchanged (0, 0); + 2.7*1.4 (c, 0); + 2t - 50*1.4 (2t, -70); float ener + t == (float)((double)ener + (double)t) because a
+     * double holds more than 2*24+2 bits (double rounding is innocuous).  X and Y are selected off the serial chain, which is
+     * then cvt - add - add - cvt. */
+    const double c_lo = (2.7) * (28.0 / 20.0), c_hi = -((50.0) * (28.0 / 20.0));
+#define GSTEP(ev) do { const float t = (ev) - fc; const bool lo = t < thr7, hi = t > thr50; const double dt = (double)t; \
+        const double x_hi = opaque_d(hi ? dt + dt : dt), x_lo = opaque_d(iszero ? 0.0 : c_lo); \
+        const double X = lo ? x_lo : x_hi, Y = opaque_d((hi && !lo) ? c_hi : 0.0); \
+        ener = (float)(((double)ener + X) + Y); iszero = iszero && lo; } while (0)
+    int j = nq - 1;
+    for (; j >= 3; j -= 4) { const float v0 = en[j], v1 = en[j - 1], v2 = en[j - 2], v3 = en[j - 3]; GSTEP(v0); GSTEP(v1); GSTEP(v2); GSTEP(v3); }
+    for (; j >= 0; j--) GSTEP(en[j]);
 #undef GSTEP
-    return ener > target && iszero == 0;
+    return ener > target && !iszero;
 }
 
 /* ---- global gain estimate R/estimate_global_gain.c:30-137 ---- */
 STAGE void st_gain_estimate(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ C, WaveLds& L, int lane, int nbitsSQ)
 {
     const int lg = PI(ylen), off = CI(gg_off), nq = lg >> 2;
+    SUB_BEGIN();
     float tbits_off = unif(L.fsc[F_TBITS_OFF]);
     int mem_target = uni(L.isc[I_MEM_TARGET]); const int mem_spec = uni(L.isc[I_MEM_SPEC]);
     if (mem_target < 0) tbits_off = 0;
@@ -1405,6 +1489,8 @@ STAGE void st_gain_estimate(const lc3d_plan* __restrict__ P, const lc3d_chan* __
         const float g_min = PI(hrmode) == 1 ? x_max / (float)(32768 * 256 - 2) : (float)((double)x_max / (32768 - 0.375));
         ind_min = (float)ceil(28.0 * (double)m_log10f(g_min));
         float* en = XCUR(L);                         /* X is scratch between TNS and quantisation */
+        SUB(10);
+        float ev[2] = {0, 0};
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const int j = lane + 64 * h;
@@ -1412,10 +1498,11 @@ STAGE void st_gain_estimate(const lc3d_plan* __restrict__ P, const lc3d_chan* __
                 const float* x = &L.A[4 * j];
                 float t = x[0] * x[0];
                 t += x[1] * x[1]; t += x[2] * x[2]; t += x[3] * x[3];
-                en[j] = (float)((28.0 / 20.0) * (7 + 10.0 * (double)m_log10f(t + reg_val + PF(c_2m31))));
+                en[j] = ev[h] = (float)((28.0 / 20.0) * (7 + 10.0 * (double)m_log10f(t + reg_val + PF(c_2m31))));
             }
         }
         LSYNC();
+        SUB(11);
         const float target = (float)((28.0 / 20.0) * (1.4) * (double)nbitsSQ);
         const float thr7 = PF(c_thr7_up), thr50 = PF(c_thr50_dn);
         const int offset0 = 255 + off;
@@ -1424,16 +1511,18 @@ STAGE void st_gain_estimate(const lc3d_plan* __restrict__ P, const lc3d_chan* __
         {
             const int lvl = lane ? ilog2((unsigned)lane) : 0, p = lane - (1 << lvl);
             const int cand = offset0 - (p << (8 - lvl)) - (128 >> lvl);
-            const unsigned long long addback = __ballot(gain_probe(thr7, thr50, en, nq, cand, offset0 - 252, target));
+            const unsigned long long addback = __ballot(gain_probe(thr7, thr50, en, gain_probe_len(thr7, ev[0], ev[1], lane, nq, offset0 - 252), cand, target));
             int node = 1;
             for (int i = 0; i < 6; i++) { const int nb = ((addback >> node) & 1ull) ? 0 : 1; m += nb << (7 - i); node = 2 * node + nb; }
         }
+        SUB(12);
         {   /* last two steps: lane 0: step 6; lane 1: step 7 if step 6 added back; lane 2: step 7 otherwise */
             const int cand = lane == 0 ? offset0 - m - 2 : lane == 1 ? offset0 - m - 1 : offset0 - m - 3;
-            const unsigned long long addback = __ballot(gain_probe(thr7, thr50, en, nq, cand, offset0 - m - 3, target));
+            const unsigned long long addback = __ballot(gain_probe(thr7, thr50, en, gain_probe_len(thr7, ev[0], ev[1], lane, nq, offset0 - m - 3), cand, target));
             if (addback & 1ull) { if (!(addback & 2ull)) m += 1; }
             else { m += 2; if (!(addback & 4ull)) m += 1; }
         }
+        SUB(13);
         const int offset = offset0 - m;
         if ((float)offset < ind_min) mem_target = -1;
         ind = (ind_min > (float)offset ? ind_min : (float)offset) - (float)off;
@@ -1444,6 +1533,7 @@ STAGE void st_gain_estimate(const lc3d_plan* __restrict__ P, const lc3d_chan* __
         L.fsc[F_GAIN] = P->gain_est[(int)(ind + (float)off) + 256];
     }
     LSYNC();
+    SUB(14);
 }
 
 /* ---- quantisation + exact bit estimate R/quantize_spec.c:26-197 ---- */
@@ -1681,44 +1771,78 @@ __device__ __forceinline__ void or_bits_fwd(uint8_t* buf, int q, unsigned v, int
     if ((unsigned)(V >> 32)) atomicOr(&W[(q >> 5) + 1], (unsigned)(V >> 32));
 }
 
-struct AriSt { int bp, low, range, cache, carry, carry_count; int fw; };
+/* ---- range coder, restated for a wavefront (R/ari_codec.c:511-660) ----
+ * The reference's coder carries (low, range, cache, carry, carry_count, bp) from symbol to symbol.  Only `range` is inherently
+ * serial: range' = (range >> 10) * freq, renormalised by whole bytes.  `low` is a sum: symbol j adds c_j = (range_j >> 10) * cum_j
+ * at the byte position s_j (the number of renormalisation shifts so far), and cache / carry / carry_count are just a streaming
+ * carry-propagation over that sum.  So:
+ *   serial   (SALU, ~9 instructions per symbol): the range chain; r_j = range_j >> 10 is left in lane j of a VGPR;
+ *   parallel (one lane per symbol): s_j by a prefix sum of the shift counts, c_j = r_j * cum_j added into the code value, a
+ *            big-endian byte string held as a multi-word integer in LDS (atomic add, carries rippled by the lane that caused them).
+ * Finalisation (ac_finalize_fl) is then an add of (val - low) at the window plus the top `bits` bits of the result. */
+#define BIGW 162                                 /* words of the code value: stream byte p is byte (BIGB - 1 - p) of big[] */
+#define BIGB (4 * BIGW)
+#define BIG(L)  ((unsigned*)&(L).A[160])         /* BIGW + 1 words (guard word on top) */
+#define SYML(L) ((unsigned*)&(L).A[324])         /* flattened symbol list of one group of tuples: cum | freq << 16 */
+#define SYMCAP 156
 
-__device__ __forceinline__ void ari_emit(AriSt& w, uint8_t* bytes, int lane, int b)
+/* v_writelane_b32 with a variable lane select: two different SGPR operands would break the constant-bus limit, M0 is exempt */
+__device__ __forceinline__ int writelane(int vec, int val, int lane_sel)
 {
-    w.fw = (lane == (w.bp & 63)) ? b : w.fw;
-    w.bp++;
-    if ((w.bp & 63) == 0) bytes[w.bp - 64 + lane] = (uint8_t)w.fw;
+    asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(vec) : "s"(val), "s"(lane_sel));   /* M0 is a reserved scratch register: the compiler never keeps a value in it across other code */
+    return vec;
 }
-__device__ __forceinline__ void ari_flush(AriSt& w, uint8_t* bytes, int lane)
+
+/* add v (< 2^25) into the code value with its bits 23..16 at stream byte s */
+__device__ __forceinline__ void big_add(unsigned* big, unsigned v, int s)
 {
-    if (lane < (w.bp & 63)) bytes[(w.bp & ~63) + lane] = (uint8_t)w.fw;
+    const int q = 8 * (BIGB - 3 - s); int w = q >> 5;
+    const unsigned long long V = (unsigned long long)v << (q & 31);
+    unsigned add = (unsigned)V;
+    unsigned old = atomicAdd(&big[w], add);
+    add = (unsigned)(V >> 32) + ((old + add) < add ? 1u : 0u); w++;
+    while (add) { old = atomicAdd(&big[w], add); add = (old + add) < add ? 1u : 0u; w++; }
 }
-__device__ __forceinline__ void ari_shift(AriSt& w, uint8_t* bytes, int lane)     /* R/ari_codec.c:531-553 */
+
+struct AriSt { int range, s8; int a0; };         /* range, 8 * shifts so far, sum of the c_j added since the last shift */
+
+/* code up to 64 symbols: lane j < cnt holds symbol j as cum | freq << 16 */
+__device__ __forceinline__ void ari_chunk(AriSt& w, unsigned* big, int lane, unsigned vsym, int cnt)
 {
-    if (w.low < 16711680 || w.carry == 1) {
-        if (w.cache >= 0) ari_emit(w, bytes, lane, w.cache + w.carry);
-        while (w.carry_count > 0) { ari_emit(w, bytes, lane, (w.carry + 255) & 255); w.carry_count--; }
-        w.cache = w.low >> 16; w.carry = 0;
-    } else w.carry_count++;
-    w.low = (w.low << 8) & 0xFFFFFF;
-}
-__device__ __forceinline__ void ari_encode(AriSt& w, uint8_t* bytes, int lane, int freq, int cum)   /* R/ari_codec.c:511-529 */
-{
-    const int r = w.range >> 10;
-    w.low += r * cum;
-    if ((w.low >> 24) == 1) w.carry = 1;
-    w.low &= 0xFFFFFF;
-    w.range = r * freq;
-    while (w.range < 65536) { w.range <<= 8; ari_shift(w, bytes, lane); }
+    const int vfreq = (int)(vsym >> 16), vcum = (int)(vsym & 0xffffu);
+    int vr = 0, rg = w.range, k = 0;
+#define ARI_STEP(kk) do { const int f_ = __builtin_amdgcn_readlane(vfreq, (kk)); const int r_ = (int)((unsigned)rg >> 10); \
+        vr = writelane(vr, r_, (kk)); rg = r_ * f_; rg <<= ((__builtin_clz(rg) - 8) & 24); } while (0)
+    for (; k + 8 <= cnt; k += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) ARI_STEP(k + u);
+    }
+    for (; k < cnt; k++) ARI_STEP(k);
+#undef ARI_STEP
+    w.range = rg;
+    const bool on = lane < cnt;
+    const int rng2 = on ? vr * vfreq : 0x10000;                         /* this symbol's range before renormalisation */
+    const int n8 = (__builtin_clz(rng2) - 8) & 24;
+    const int incl = wave_incl_scan_i(n8, lane);
+    const int tot = __builtin_amdgcn_readlane(incl, 63);
+    const int sk8 = w.s8 + incl - n8, s8_end = w.s8 + tot;
+    const unsigned c = on ? (unsigned)(vr * vcum) : 0u;
+    if (c) big_add(big, c, sk8 >> 3);
+    w.a0 = (tot == 0 ? w.a0 : 0) + wave_sum_i(sk8 == s8_end ? (int)c : 0);
+    w.s8 = s8_end;
 }
 
 STAGE void st_bitstream(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ C, WaveLds& L, int lane)
 {
     int* isc = L.isc;
     uint8_t* bytes = BYTES(L);
-    for (int i = lane; i < 160; i += WAVE) ((uint32_t*)bytes)[i] = 0;      /* 640 B >= the largest frame (625 B, hrmode); the spectrum in A is dead from here on */
-    LSYNC();
+    unsigned* big = BIG(L); unsigned* syml = SYML(L);
+    SUB_BEGIN();
     const int nbytes = CI(nbytes);
+    /* the spectrum in A is dead from here on: clear the frame (whole words up to nbytes) and the words of the code value a
+     * frame of nbytes can reach */
+    for (int i = lane; i < (nbytes >> 2) + 3; i += WAVE) { ((uint32_t*)bytes)[i] = 0; big[BIGW - i] = 0; }
+    LSYNC();
     const int nfilt = uni(isc[I_TNS_NF]);
     const int lastnz = uni(isc[I_LASTNZ]), lsbMode = uni(isc[I_LSB]), nres = uni(isc[I_NRES]);
     const int bw_idx = uni(isc[I_BW]), gg = uni(isc[I_GG]), fac_ns = uni(isc[I_FACNS]);
@@ -1761,38 +1885,43 @@ STAGE void st_bitstream(const lc3d_plan* __restrict__ P, const lc3d_chan* __rest
         or_bits_back(bytes, nbytes, 32 * lane, piece, imin(32, Q - 32 * lane));
     }
     if (lane == 0) { isc[I_BP_SIDE] = nbytes - 1 - (Q >> 3); isc[I_MASK_SIDE] = 1 << (Q & 7); }
+    SUB(15);
 
-    /* ---- range coder: TNS symbols ---- */
-    AriSt w; w.bp = 0; w.low = 0; w.range = 0xFFFFFF; w.cache = -1; w.carry = 0; w.carry_count = 0; w.fw = 0;
-    for (int i = 0; i < nfilt; i++) {
-        const int ord = uni(isc[I_TNS_ORD0 + i]);
-        if (ord > 0) {
-            const uint16_t* oc = &lc3t_tns_order_cum[CI(lpc_weighting) * 9];
-            ari_encode(w, bytes, lane, uni(oc[ord] - oc[ord - 1]), uni(oc[ord - 1]));
-            for (int j = 0; j < ord; j++) {
-                const uint16_t* cc = &lc3t_tns_coef_cum[j * 18]; const int id = uni(isc[I_TNS_IDX0 + i * 8 + j]);
-                ari_encode(w, bytes, lane, uni(cc[id + 1] - cc[id]), uni(cc[id]));
-            }
+    /* ---- range coder: TNS symbols (order, then coefficients, per filter) ---- */
+    AriSt w; w.range = 0xFFFFFF; w.s8 = 0; w.a0 = 0;
+    {
+        const int ord0 = nfilt > 0 ? uni(isc[I_TNS_ORD0]) : 0, ord1 = nfilt > 1 ? uni(isc[I_TNS_ORD1]) : 0;
+        const int n0 = ord0 > 0 ? ord0 + 1 : 0, n1 = ord1 > 0 ? ord1 + 1 : 0, nt = n0 + n1;
+        if (nt > 0) {
+            const int f = lane < n0 ? 0 : 1, j = (f ? lane - n0 : lane) - 1, ord = f ? ord1 : ord0;
+            unsigned sv = 0;
+            if (lane < nt) sv = j < 0 ? lc3t_tns_order_sym[CI(lpc_weighting) * 8 + ord - 1] : lc3t_tns_coef_sym[j * 17 + isc[I_TNS_IDX0 + f * 8 + j]];
+            ari_chunk(w, big, lane, sv, nt);
         }
     }
+    SUB(16);
     /* ---- spectrum: 64 tuples per pass ---- */
     const int ntup = (lastnz + 1) >> 1;
     int nl = 0;                                   /* LSB-mode list length */
     for (int c0 = 0; c0 < ntup; c0 += WAVE) {
         const int p = c0 + lane; const bool act = p < ntup;
         const uint32_t cdv = act ? cdw[p] : 0u;
-        unsigned cfv = 0;
-        if (act) { const uint16_t* q = &lc3t_ac_cum[((cdv >> 16) & 63) * 18 + ((cdv >> 22) & 31)]; cfv = q[0] | ((unsigned)(q[1] - q[0]) << 16); }
+        const unsigned fsym = act ? lc3t_ac_sym[((cdv >> 16) & 63) * 17 + ((cdv >> 22) & 31)] : 0u;
         const int x0 = act ? xq[2 * p] : 0, x1 = act ? xq[2 * p + 1] : 0;
         const int a0 = x0 < 0 ? -x0 : x0, b0 = x1 < 0 ? -x1 : x1;
         const int ctx = cdv & 1023, maxlev = act ? (int)((cdv >> 10) & 63) - 1 : -1;
-        /* escape symbol models for level classes 0..3 */
+        const int nesc = maxlev > 0 ? maxlev : 0;
+        /* escape symbol (16) of the models of level classes 0..3; loads are issued only when some lane needs them */
         unsigned e0 = 0, e1 = 0, e2 = 0, e3 = 0;
-        if (maxlev > 0) {
-            { const uint16_t* q = &lc3t_ac_cum[lc3t_ac_ctx_lut[ctx] * 18]; e0 = q[16] | ((unsigned)(q[17] - q[16]) << 16); }
-            if (maxlev > 1) { const uint16_t* q = &lc3t_ac_cum[lc3t_ac_ctx_lut[ctx + 1024] * 18]; e1 = q[16] | ((unsigned)(q[17] - q[16]) << 16); }
-            if (maxlev > 2) { const uint16_t* q = &lc3t_ac_cum[lc3t_ac_ctx_lut[ctx + 2048] * 18]; e2 = q[16] | ((unsigned)(q[17] - q[16]) << 16); }
-            if (maxlev > 3) { const uint16_t* q = &lc3t_ac_cum[lc3t_ac_ctx_lut[ctx + 3072] * 18]; e3 = q[16] | ((unsigned)(q[17] - q[16]) << 16); }
+        if (__ballot(nesc > 0)) {
+            if (nesc > 0) e0 = lc3t_ac_sym[lc3t_ac_ctx_lut[ctx] * 17 + 16];
+            if (__ballot(nesc > 1)) {
+                if (nesc > 1) e1 = lc3t_ac_sym[lc3t_ac_ctx_lut[ctx + 1024] * 17 + 16];
+                if (__ballot(nesc > 2)) {
+                    if (nesc > 2) e2 = lc3t_ac_sym[lc3t_ac_ctx_lut[ctx + 2048] * 17 + 16];
+                    if (nesc > 3) e3 = lc3t_ac_sym[lc3t_ac_ctx_lut[ctx + 3072] * 17 + 16];
+                }
+            }
         }
         /* backward bits of this tuple: escape LSB pairs, then signs (R/ari_codec.c:700-757) */
         unsigned long long bits = 0; int n = 0;
@@ -1813,78 +1942,95 @@ STAGE void st_bitstream(const lc3d_plan* __restrict__ P, const lc3d_chan* __rest
         if (b != 0) { bits |= (unsigned long long)(x1 < 0) << n; n++; }
         const int incl = wave_incl_scan_i(n, lane);
         or_bits_back(bytes, nbytes, Q + incl - n, bits, n);
-        Q += uni(__shfl(incl, 63));
+        Q += __builtin_amdgcn_readlane(incl, 63);
         if (lsbMode == 1) {
             const int li = wave_incl_scan_i(ln, lane);
             or_bits_fwd(resb, nl + li - ln, lsbv, ln);
-            nl += uni(__shfl(li, 63));
+            nl += __builtin_amdgcn_readlane(li, 63);
         }
-        /* serial part: wave-uniform scalar code; runs of escape-free tuples take the short loop */
-        const int cnt = uni(imin(WAVE, ntup - c0));
-        const unsigned long long escm = __ballot(maxlev > 0);
-        int j = 0;
-        while (j < cnt) {
-            const unsigned long long rest = escm >> j;
-            const int e = imin(cnt, j + (rest ? (int)__ffsll((long long)rest) - 1 : 64));
-            for (; j < e; j++) {
-                const unsigned fv = (unsigned)__builtin_amdgcn_readlane((int)cfv, j);
-                ari_encode(w, bytes, lane, (int)(fv >> 16), (int)(fv & 0xffff));
-            }
-            if (j < cnt) {
-                const int ml = __builtin_amdgcn_readlane(maxlev, j);
-                for (int lev = 0; lev < ml; lev++) {
-                    const unsigned ev = lev == 0 ? (unsigned)__builtin_amdgcn_readlane((int)e0, j) : lev == 1 ? (unsigned)__builtin_amdgcn_readlane((int)e1, j)
-                                      : lev == 2 ? (unsigned)__builtin_amdgcn_readlane((int)e2, j) : (unsigned)__builtin_amdgcn_readlane((int)e3, j);
-                    ari_encode(w, bytes, lane, (int)(ev >> 16), (int)(ev & 0xffff));
-                }
-                const unsigned fv = (unsigned)__builtin_amdgcn_readlane((int)cfv, j);
-                ari_encode(w, bytes, lane, (int)(fv >> 16), (int)(fv & 0xffff));
-                j++;
-            }
+        /* flatten the pass into the symbol list: per tuple its escape symbols in level order, then the final symbol.  The list
+         * holds SYMCAP symbols; a pass with more (many escapes) goes through it in groups of 16 or 4 tuples. */
+        const int ns = act ? 1 + nesc : 0;
+        const int sincl = wave_incl_scan_i(ns, lane);
+        const int M = __builtin_amdgcn_readlane(sincl, 63);
+        int G = WAVE;
+        if (M > SYMCAP) {
+            const int q0 = __builtin_amdgcn_readlane(sincl, 15), q1 = __builtin_amdgcn_readlane(sincl, 31), q2 = __builtin_amdgcn_readlane(sincl, 47);
+            G = (q0 <= SYMCAP && q1 - q0 <= SYMCAP && q2 - q1 <= SYMCAP && M - q2 <= SYMCAP) ? 16 : 4;
         }
+        SUB(17);
+        const int cntT = imin(WAVE, ntup - c0);
+        for (int g0 = 0; g0 < cntT; g0 += G) {
+            const int gl = g0 + G - 1;
+            const int base = g0 ? __builtin_amdgcn_readlane(sincl, g0 - 1) : 0, Mg = __builtin_amdgcn_readlane(sincl, gl) - base;
+            if (act && lane >= g0 && lane <= gl) {
+                const int o = sincl - ns - base;
+                for (int lev = 0; lev < nesc; lev++) syml[o + lev] = lev == 0 ? e0 : lev == 1 ? e1 : lev == 2 ? e2 : e3;
+                syml[o + nesc] = fsym;
+            }
+            LSYNC();
+            for (int k0 = 0; k0 < Mg; k0 += WAVE) {
+                const int cnt = imin(WAVE, Mg - k0);
+                ari_chunk(w, big, lane, lane < cnt ? syml[k0 + lane] : 0u, cnt);
+            }
+            LSYNC();
+        }
+        SUB(18);
     }
-    /* ---- residual / LSB bits (R/ari_codec.c:764-797) ---- */
+    /* ---- residual / LSB bits (R/ari_codec.c:764-797); bp + pending bytes of the reference = number of shifts ---- */
     const int total = CI(total_bits);
     const int bp_side = nbytes - 1 - (Q >> 3), mask_log = Q & 7;
     const int nbits_side = total - (8 * (bp_side + 1) + 8 - mask_log);
-    int nbits_ari = (w.bp + 1) * 8 + 25 - flog2f_int((unsigned)w.range);
-    if (w.cache >= 0) nbits_ari += 8;
-    if (w.carry_count > 0) nbits_ari += w.carry_count * 8;
+    const int S = w.s8 >> 3;
+    const int nbits_ari = 8 * S + 33 - flog2f_int((unsigned)w.range);
     int nres_enc = total - (nbits_side + nbits_ari);
     nres_enc = imin(nres_enc, lsbMode == 0 ? nres : nl);
-    LSYNC();                                        /* LSB list / residual bits are complete */
+    LSYNC();                                        /* LSB list / residual bits and the code value are complete */
     for (int k0 = 32 * lane; k0 < nres_enc; k0 += 32 * WAVE) {
         const unsigned wv = ((const unsigned*)resb)[k0 >> 5];
         or_bits_back(bytes, nbytes, Q + k0, wv, imin(32, nres_enc - k0));
     }
-    /* ---- finalise the range coder (R/ari_codec.c:573-647) ---- */
+    SUB(19);
+    /* ---- finalise (R/ari_codec.c:573-647) ---- */
+    const uint8_t* bb = (const uint8_t*)big;
+    const int low = (bb[BIGB - 1 - S] << 16) | (bb[BIGB - 2 - S] << 8) | bb[BIGB - 3 - S];
+    /* carry flag of the reference at this point: did the adds since the last shift leave the 24-bit window? */
+    const int c_pending = (int)(((((unsigned)low - (unsigned)w.a0) & 0xFFFFFFu) + (unsigned)w.a0) >> 24);
     int bits = 24 - flog2f_int((unsigned)w.range);
-    int mask = 0xFFFFFF >> bits, val = w.low + mask, over1 = val >> 24;
+    int mask = 0xFFFFFF >> bits, val = low + mask; const int over1 = val >> 24;
     val &= 0xFFFFFF;
-    int high = w.low + w.range, over2 = high >> 24;
+    int high = low + w.range; const int over2 = high >> 24;
     high &= 0xFFFFFF;
     val &= (0xFFFFFF - mask);
+    int cf = 0;
     if (over1 == over2) {
-        if (val + mask >= high) { bits++; mask >>= 1; val = ((w.low + mask) & 0xFFFFFF) & (0xFFFFFF - mask); }
-        if (val < w.low) w.carry = 1;
+        if (val + mask >= high) { bits++; mask >>= 1; val = ((low + mask) & 0xFFFFFF) & (0xFFFFFF - mask); }
+        if (val < low) cf = 1;
     }
-    w.low = val;
-    int b = bits;
-    if (bits > 8) { for (; b >= 1; b -= 8) ari_shift(w, bytes, lane); } else ari_shift(w, bytes, lane);
-    bits = b; if (bits < 0) bits += 8;
-    int last; const int nb = bits;
-    if (w.carry_count > 0) {
-        ari_emit(w, bytes, lane, w.cache);
-        for (int c = w.carry_count; c >= 2; c--) ari_emit(w, bytes, lane, 255);
-        last = 255 << (bits - 8);
-    } else last = w.cache;
-    ari_flush(w, bytes, lane);
-    LSYNC();                                        /* all forward bytes and backward ORs have landed */
-    if (lane == 0) {
-        uint8_t v = bytes[w.bp];
-        for (int k = 0, m = 128; k < nb; k++, m >>= 1) { if ((last & m) == 0) v &= (uint8_t)(255 - m); else v |= (uint8_t)m; }
-        bytes[w.bp] = v;
+    LSYNC();                                        /* `low` has been read by every lane */
+    if (lane == 0) { const unsigned D = (unsigned)(val - low + (cf << 24)); if (D) big_add(big, D, S); }
+    /* the final shifts: 1, or ceil(bits / 8) when bits > 8; nb = bits of the last byte that belong to the coder.  The reference
+     * ends in its carry_count > 0 branch iff the last shift found 0xFF on top of `low` with no carry pending; it then takes the
+     * bits from 255 << (nb - 8), a negative shift count that the hardware reduces mod 32: nb < 8 yields zeros. */
+    int n_f = 1, nb = bits;
+    if (bits > 8) { n_f = (bits + 7) >> 3; nb = bits - 8 * n_f; }
+    if (nb < 0) nb += 8;
+    bool ff_last = false;
+    { int lv = val, cin = c_pending | cf;
+      for (int i = 0; i < n_f; i++) { ff_last = (lv >= 0xFF0000) && cin == 0; cin = 0; lv = (lv << 8) & 0xFFFFFF; } }
+    const int F = S + n_f;                          /* forward bytes, the last one partial */
+    unsigned lastm = nb ? (0xFFu << (8 - nb)) & 0xFFu : 0u;
+    if (ff_last && nb < 8) lastm = 0;
+    LSYNC();
+    for (int k = lane; 4 * k < F; k += WAVE) {
+        const unsigned fw = __builtin_bswap32(big[BIGW - 1 - k]);
+        const int full = imin(4, imax(0, F - 1 - 4 * k));
+        unsigned mw = full >= 4 ? 0xFFFFFFFFu : ((1u << (8 * full)) - 1u);
+        if (full < 4 && 4 * k + full == F - 1) mw |= lastm << (8 * full);
+        ((unsigned*)bytes)[k] |= fw & mw;
     }
+    LSYNC();
+    SUB(20);
 }
 
 

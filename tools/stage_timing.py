@@ -16,11 +16,20 @@ pcm = synth_pcm(B, T, 480, 48000, seed=3)
 b = api.Batch(B, 48000, 1, 10.0, 0, [br] * B, device=0)
 out, tr = b.encode_traced(pcm)
 tsz = tr.shape[1]
-acc = np.zeros(24)
+SUBS = {0: "resample: FIR", 1: "resample: biquad products", 2: "resample: biquad chain", 3: "resample: history slide",
+        4: "sns_vq: stage 1", 5: "sns_vq: DCT-II", 6: "sns_vq: pulse searches", 7: "sns_vq: gains + IDCT", 8: "sns_vq: errors + select",
+        9: "sns_vq: MPVQ index", 10: "gain_est: x_max / regulariser", 11: "gain_est: band energies (log10)", 12: "gain_est: probe (6 levels)",
+        13: "gain_est: probe (last 2)", 14: "gain_est: tail", 15: "bitstream: clear + side info", 16: "bitstream: TNS symbols",
+        17: "bitstream: tuple prep (parallel)", 18: "bitstream: range coder (serial)", 19: "bitstream: residual bits", 20: "bitstream: finalise"}
+accall = np.zeros(64)
 for s in range(B):
-    acc += np.frombuffer(tr[s * T].tobytes()[:24 * 8], dtype=np.int64)
-acc = acc / (B * T)
+    accall += np.frombuffer(tr[s * T].tobytes()[:64 * 8], dtype=np.int64)
+accall = accall / (B * T)
+acc = accall[:24]
 tot = acc.sum()
 print("kernel %.3f ms for %d streams x %d frames; mean cycles/frame/wave = %.0f" % (b.last_kernel_ms(), B, T, tot))
 for n, v in zip(NAMES, acc):
     print("  %-16s %10.0f  %5.1f %%" % (n, v, 100 * v / tot))
+print("sub-stage stamps (cycles/frame):")
+for k in sorted(SUBS):
+    print("  %-36s %10.0f" % (SUBS[k], accall[24 + k]))
