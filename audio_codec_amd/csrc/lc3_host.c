@@ -183,6 +183,10 @@ static void build_plan(const geom_t* g, lc3d_plan* p)
     p->rs_mem_in_len = 2 * 8 * g->fs / 12800;                              /* R/setup_enc_lc3.c:48 */
     p->rs_stride = lc3t_rs_upfac[g->fs_idx]; p->rs_scale = lc3t_rs_scale[g->fs_idx];
     p->len12 = g->dms == 25 ? 32 : g->dms == 50 ? 64 : 128; p->n12 = g->N * 12800 / g->fs;
+    {   /* polyphase view of the resampler filter: output n uses phase start = (stride - 15n % stride) % stride, taps lp[239 - start - m*stride] */
+        const int st = p->rs_stride, T = 240 / st;
+        for (int ph = 0; ph < st; ph++) for (int m = 0; m < T; m++) p->rs_taps[ph * T + m] = lc3t_rs_lp[239 - ph - m * st];
+    }
     p->ltpf_mem_len = g->dms == 25 ? 232 + 32 : 232;
     p->att_nblocks = g->att_nblocks; p->att_hang = g->att_hang; p->att_damping = g->att_damping; p->sns_damping = g->sns_damping;
     p->bw_cls = g->dms == 25 ? 0 : g->dms == 50 ? 1 : 2;

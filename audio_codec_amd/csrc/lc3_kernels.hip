@@ -132,6 +132,7 @@ template <int CTRL, int RM = 0xF> __device__ __forceinline__ float dpp_f(float o
 #define DPP_SHR8 0x118
 #define DPP_BC15 0x142
 #define DPP_BC31 0x143
+#define DPP_WSHR1 0x138      /* wave_shr:1: lane n takes lane n-1 across row boundaries */
 __device__ __forceinline__ int wave_incl_scan_i(int v, int lane)
 {
     (void)lane;
@@ -334,29 +335,42 @@ __device__ __forceinline__ double rl_d(double v, int l)
 /* ---- 12.8 kHz resampler + 50 Hz high-pass: R/resamp12k8.c:13-84.  Appends len12 samples to h12. ---- */
 STAGE void st_resample(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
 {
-    const int mlen = PI(rs_mem_in_len), stride = PI(rs_stride), n12 = PI(n12), len12 = PI(len12);
+    const int mlen = PI(rs_mem_in_len), stride = PI(rs_stride), n12 = PI(n12), len12 = PI(len12), N = PI(N);
     const float sf = PF(rs_scale);
     const float* buf = &L.xbuf[MEMCAP - mlen];      /* [mem_in | x] */
-    float d[2] = {0, 0};
     SUB_BEGIN();
+    /* polyphase FIR, R/resamp12k8.c:48-57: out[n] = sum_m (buf[.]*sf) * lp[.] in the reference's tap order.  The scaled samples
+     * are formed once (sm is idle here); a lane's two outputs (n = lane, lane + 64) share one phase, whose taps are held in
+     * registers 30 at a time. */
+    float* xs = L.sm;
+    for (int j = lane; j < mlen + N; j += WAVE) xs[j] = buf[j] * sf;
+    LSYNC();
+    float d[2] = {0, 0};
+    {
+        const int T = 240 / stride;
+        const int i0 = 15 * lane, r = i0 % stride, start = r ? stride - r : 0;
+        const float* tp = &P->rs_taps[start * T];
+        const float* b0 = xs + (i0 + start) / stride; const float* b1 = xs + (i0 + 15 * 64 + start) / stride;
+        const bool on0 = lane < n12, on1 = lane + 64 < n12;
+        if (!on0) b0 = xs;                            /* idle lanes read in bounds */
+        if (!on1) b1 = xs;
+        float m0 = 0, m1 = 0;
+        for (int tb = 0; tb < T; tb += 30) {
+            float tap[30];
 #pragma unroll
-    for (int h = 0; h < 2; h++) {                   /* one polyphase FIR output per lane and half: taps in the reference's order */
-        const int n = lane + 64 * h;
-        if (n < n12) {
-            const int i = 15 * n, r = i % stride, start = r ? stride - r : 0;
-            const float* bp = buf + (i + start) / stride; const float* fp = &lc3t_rs_lp[239 - start];
-            const int cnt = (240 - start + stride - 1) / stride;
-            float mac = 0;
-#pragma unroll 12
-            for (int m = 0; m < cnt; m++) mac += bp[m] * sf * fp[-m * stride];
-            d[h] = mac;
+            for (int m = 0; m < 30; m++) tap[m] = tp[tb + m];
+#pragma unroll
+            for (int m = 0; m < 30; m++) { m0 += b0[tb + m] * tap[m]; m1 += b1[tb + m] * tap[m]; }
         }
+        d[0] = on0 ? m0 : 0.0f; d[1] = on1 ? m1 : 0.0f;
     }
-    /* biquad in double, strictly serial (R/resamp12k8.c:60-74): the x-only products b_k*x are formed per lane and parked in LDS
-     * (A and sm are idle here), the recurrence streams them back with uniform-address reads (LDS issue, not VALU issue) */
     SUB(0);
+    /* biquad in double, strictly serial (R/resamp12k8.c:60-74): the x-only products b_k*x are formed per lane and parked in LDS
+     * (A and sm are idle here), the recurrence streams them back with uniform-address reads, one group of four steps ahead of
+     * the arithmetic; each output goes back through LDS (a uniform-address store) instead of a per-step lane select */
     const double b0 = lc3t_hp50_b[0], b1 = lc3t_hp50_b[1], b2 = lc3t_hp50_b[2], a1 = lc3t_hp50_a[1], a2 = lc3t_hp50_a[2];
-    double* q0 = (double*)L.A; double* q1 = (double*)L.sm; double* q2 = q1 + 128;
+    double* q0 = (double*)L.A; double* q1 = (double*)L.sm; double* q2 = q1 + 128; float* yo = &L.A[256];
+    LSYNC();                                          /* xs (in sm) is dead */
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         const int n = lane + 64 * h;
@@ -364,20 +378,31 @@ STAGE void st_resample(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
     }
     LSYNC();
     double u11 = (double)L.fsc[F_HP0], u21 = (double)L.fsc[F_HP1];
-    float y[2] = {0, 0};
     SUB(1);
+    {
+        double c0[4], c1[4], c2[4];
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
-        const int cnt = imin(len12 - 64 * h, 64);
-#pragma unroll 4
-        for (int i = 0; i < cnt; i++) {
-            const double y1 = (q0[64 * h + i] + u11);
-            const double u1 = (q1[64 * h + i] + u21) - a1 * y1;
-            const double u2 = q2[64 * h + i] - a2 * y1;
-            u11 = u1; u21 = u2;
-            y[h] = (lane == i) ? (float)y1 : y[h];
+        for (int k = 0; k < 4; k++) { c0[k] = q0[k]; c1[k] = q1[k]; c2[k] = q2[k]; }
+        for (int g = 0; g < len12; g += 4) {
+            const int gn = g + 4 < len12 ? g + 4 : g;      /* the last group re-reads itself: no branch around the prefetch */
+            double n0[4], n1[4], n2[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { n0[k] = q0[gn + k]; n1[k] = q1[gn + k]; n2[k] = q2[gn + k]; }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const double y1 = c0[k] + u11;
+                const double u1 = (c1[k] + u21) - a1 * y1;
+                const double u2 = c2[k] - a2 * y1;
+                u11 = u1; u21 = u2;
+                yo[g + k] = (float)y1;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) { c0[k] = n0[k]; c1[k] = n1[k]; c2[k] = n2[k]; }
         }
     }
+    LSYNC();
+    float y[2];
+    y[0] = lane < len12 ? yo[lane] : 0.0f; y[1] = lane + 64 < len12 ? yo[lane + 64] : 0.0f;
     SUB(2);
     float keep[6];
 #pragma unroll
@@ -413,6 +438,7 @@ __device__ __forceinline__ float olpa_normcorr(WaveLds& L, const float* s6, int 
 STAGE void st_olpa(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
 {
     const int len = PI(len12), len2 = len >> 1;
+    SUB_BEGIN();
     int acf = len2, back = 0;
     if (PI(dms) == 25) { acf += 16; back = 16; }
     float nd = 0;
@@ -432,6 +458,7 @@ STAGE void st_olpa(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
     for (int k = 0; k < 4; k++) { const int i = lane + 64 * k; if (i + len2 < 194) L.h6[i] = keep[k]; }
     if (lane < len2) L.h6[194 - len2 + lane] = nd;
     LSYNC();
+    SUB(25);
     const float* s6 = &L.h6[194 - len2 - back];
     float* R0 = &L.sm[SM_MISC];                     /* 98 unweighted autocorrelations */
     const bool two = lane < 34;
@@ -446,6 +473,7 @@ STAGE void st_olpa(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
     wave_argmax_first<64>(best, besti);
     int T0 = uni(besti) + 17;
     LSYNC();
+    SUB(26);
     float nc = olpa_normcorr(L, s6, acf, T0, lane, PF(c_1em5_a));
     const int old = uni(L.isc[I_OLPA_PITCH]);
     const int lo = imax(17, old - 4), hi = imin(114, old + 4), cnt = hi - lo + 1;
@@ -458,6 +486,7 @@ STAGE void st_olpa(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
     }
     if (lane == 0) { L.isc[I_OLPA_PITCH] = T0; L.isc[I_T0] = (int)(T0 * 2.0); L.fsc[F_NC] = nc; }
     LSYNC();
+    SUB(27);
 }
 
 /* ---- LTPF parameter coder: R/ltpf_coder.c:34-263 ---- */
@@ -913,48 +942,51 @@ STAGE void st_sns_scf(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
  * decision is a select, because a divergent branch costs more than the whole 16-candidate chain step it would skip. */
 __device__ __forceinline__ void pvq_search_reg(WaveLds& L, const float* x_in, int dim, int pulses, int* y_out, float* yn_out)
 {
-    float xabs[16]; int y[16];
-    float xsum = 0, yy = 0, xy = 0; unsigned negm = 0;
+    float xabs[16], yf[16];                          /* yf: pulse counts as floats (small integers, exact) */
+    float xsum = 0, yy = 0, xy = 0, totf = 0; unsigned negm = 0;
 #pragma unroll
-    for (int i = 0; i < 16; i++) { const float xv = x_in[i]; xabs[i] = i < dim ? fabsf(xv) : 0.0f; negm |= (xv >= 0 ? 0u : 1u) << i; y[i] = 0; }
+    for (int i = 0; i < 16; i++) { const float xv = x_in[i]; xabs[i] = i < dim ? fabsf(xv) : 0.0f; negm |= (xv >= 0 ? 0u : 1u) << i; }
 #pragma unroll
     for (int i = 0; i < 16; i++) xsum += xabs[i];
     const bool live = xsum > PF(c_2m24);
-    int tot = live ? 0 : pulses;
     const float proj = live ? (float)(pulses - 1) / xsum : 0.0f;
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-        const int yi = (int)floorf(xabs[i] * proj);
-        y[i] = yi; tot += yi;
-        yy = yy + (float)(yi * yi);
-        xy = xy + xabs[i] * (float)yi;
+        const float yi = floorf(xabs[i] * proj);
+        yf[i] = yi; totf += yi;
+        yy = yy + yi * yi;
+        xy = xy + xabs[i] * yi;
     }
+    int tot = live ? (int)totf : pulses;
+    /* dimensions beyond dim must never win the scan: +INF as their pulse count makes b = INF, and a*cden > INF*cnum is false for
+     * every cnum >= 0 (INF*0 = NaN compares false); cnum is >= 0 from candidate 0 on, which always exists */
+#pragma unroll
+    for (int i = 0; i < 16; i++) yf[i] = i < dim ? yf[i] : INFINITY;
     yy = yy * 0.5f;
     while (tot < pulses) {
-        int imx = 0; float cnum = -PF(c_2p15), cden = 0, xs = 0; int ys = 0;
+        int imx = 0; float cnum = -PF(c_2p15), cden = 0, xs = 0, ys = 0;
         yy = yy + 0.5f;
 #pragma unroll
         for (int i = 0; i < 16; i++) {
             float a = xy + xabs[i]; a = a * a;
-            const float b = yy + (float)y[i];
-            const bool t = (i < dim) & (a * cden > b * cnum);
-            cnum = t ? a : cnum; cden = t ? b : cden; imx = t ? i : imx; xs = t ? xabs[i] : xs; ys = t ? y[i] : ys;
+            const float b = yy + yf[i];
+            const bool t = a * cden > b * cnum;
+            cnum = t ? a : cnum; cden = t ? b : cden; imx = t ? i : imx; xs = t ? xabs[i] : xs; ys = t ? yf[i] : ys;
         }
 #pragma unroll
-        for (int i = 0; i < 16; i++) y[i] += (i == imx) ? 1 : 0;
-        xy = xy + xs; yy = yy + (float)ys; tot++;
+        for (int i = 0; i < 16; i++) yf[i] += (i == imx) ? 1.0f : 0.0f;
+        xy = xy + xs; yy = yy + ys; tot++;
     }
     yy = yy * 2.0f;
-    if (!live) {
-        /* all-zero target: the reference puts the pulses at y[0] and (out of range) y[dim]; only y[0] is ever read back */
-        const int y0 = pulses / 2, yd = -(pulses - pulses / 2);
-        y[0] = y0;
-        yy = (float)(y0 * y0 + yd * yd);
-    }
+    /* all-zero target: the reference puts the pulses at y[0] and (out of range) y[dim]; only y[0] is ever read back */
+    const int y0z = pulses / 2, ydz = -(pulses - pulses / 2);
+    if (!live) yy = (float)(y0z * y0z + ydz * ydz);
     const float g = (float)(1.0 / (double)sqrtf(yy));
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-        const int yi = ((negm >> i) & 1u) ? -y[i] : y[i];      /* y[i] is 0 beyond dim */
+        int ya = i < dim ? (int)yf[i] : 0;
+        if (i == 0) ya = live ? ya : y0z;
+        const int yi = ((negm >> i) & 1u) ? -ya : ya;
         y_out[i] = yi; yn_out[i] = (float)yi * g;
     }
 }
@@ -1352,29 +1384,42 @@ STAGE void tns_sums(WaveLds& L, int lane, int bw_idx, int bw_bin)
 {
     const TnsGeom G = tns_geom(L, bw_idx, bw_bin);
     float* racc = &L.sm[SM_MISC];              /* [f][sub][k] 2*3*9 = 54, sub-division energies 6 at +54, r[f][9] at +64 */
-    {   /* one serial sum per lane: lanes 0..53 autocorrelation terms, 54..59 sub-division energies (R/tns_coder.c:18-39,258-277) */
-        int f, sub, k = -1;
-        if (lane < 54) { f = lane / 27; const int r = lane % 27; sub = r / 9; k = r % 9; }
-        else { const int r = lane - 54; f = r / 3; sub = r % 3; }
-        if (lane < 60 && f < G.numfilters && sub < G.nSub && (k <= G.maxOrder)) {
-            const int fstart = f ? G.start1 : G.start0, fstop = f ? G.stop1 : G.stop0;
-            const float sublen = (float)(((double)(float)fstop + 1.0 - (double)(float)fstart) / (double)(float)G.nSub);
-            const int lo = (int)(floor((double)(sublen * (float)sub)) + fstart - 1);
-            const int hi = (int)(floor((double)(sublen * (float)(sub + 1))) + fstart - 1);
-            const float* x = &L.A[lo]; const int n = hi - lo;
-            float acc = 0;
-            if (k < 0) {
-#pragma unroll 8
-                for (int i = 0; i < n; i++) acc += x[i] * x[i];
-                racc[54 + f * 3 + sub] = acc;
-            } else {
-                const float* xk = x - k;
-#pragma unroll 8
-                for (int i = k; i < n; i++) acc += x[i] * xk[i];
-                racc[lane] = acc;
+    {   /* one serial sum per lane: lane (f, sub, k) < 54 owns autocorrelation lag k of a sub-division (R/tns_coder.c:18-39,258-277);
+         * the sub-division energies are the lag-0 sums (same terms, same order).  Eight terms per block; the operands of the next
+         * block are read before the arithmetic of the current one. */
+        const int f = lane / 27, r = lane % 27, sub = r / 9, k = r % 9;
+        const bool on = lane < 54 && f < G.numfilters && sub < G.nSub && k <= G.maxOrder;
+        const int fstart = f ? G.start1 : G.start0, fstop = f ? G.stop1 : G.stop0;
+        const float sublen = (float)(((double)(float)fstop + 1.0 - (double)(float)fstart) / (double)(float)G.nSub);
+        const int lo = (int)(floor((double)(sublen * (float)sub)) + fstart - 1);
+        const int hi = (int)(floor((double)(sublen * (float)(sub + 1))) + fstart - 1);
+        const int cnt = on ? hi - lo - k : 0;                         /* terms x[i] * x[i-k], i = k .. n-1 */
+        const float* pb = on ? &L.A[lo] : &L.A[0]; const float* pa = pb + (on ? k : 0);
+        const int cmax = wave_max_i(cnt), cmin = -wave_max_i(on ? -cnt : -0x7fff);
+        float acc = 0;
+        int t0 = 0;
+        if (cmin >= 8) {
+            float ca[8], cb[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) { ca[j] = pa[j]; cb[j] = pb[j]; }
+            for (; t0 + 8 <= cmin; t0 += 8) {
+                float na[8], nb[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) { na[j] = pa[t0 + 8 + j]; nb[j] = pb[t0 + 8 + j]; }     /* at most 15 floats past a run: inside A */
+#pragma unroll
+                for (int j = 0; j < 8; j++) acc += ca[j] * cb[j];
+#pragma unroll
+                for (int j = 0; j < 8; j++) { ca[j] = na[j]; cb[j] = nb[j]; }
             }
         }
+        for (; t0 < cmax; t0 += 8) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) { const float pr = pa[t0 + j] * pb[t0 + j]; acc += (t0 + j < cnt) ? pr : 0.0f; }
+        }
+        if (on) racc[lane] = acc;
     }
+    LSYNC();
+    if (lane < 6) racc[54 + lane] = racc[(lane / 3) * 27 + (lane % 3) * 9];
     LSYNC();
     if (lane < 18) {   /* r[f][k] with the reference's zero-energy escape, lag window */
         const int f = lane / 9, k = lane % 9;
@@ -1397,16 +1442,21 @@ STAGE void tns_sums(WaveLds& L, int lane, int bw_idx, int bw_bin)
  * save registers to scratch, i.e. HBM write traffic that is not part of the algorithm) */
 __device__ __forceinline__ void st_tns(const lc3d_plan* __restrict__ P, WaveLds& L, int lane, int bw_idx, int bw_bin)
 {
+    SUB_BEGIN();
     tns_sums(L, lane, bw_idx, bw_bin);
+    SUB(21);
     const TnsGeom G = tns_geom(L, bw_idx, bw_bin);
     int bits = 0;
     for (int f = 0; f < G.numfilters; f++) {
         const int code = tns_levinson(L, lane, f, G.maxOrder, G.maxPG);
         if (code == 2) tns_lpc_weight(L, lane, G.maxOrder, G.maxPG, unif(L.sm[SM_MISC + 112 + 63]));
+        SUB(22);
         bits += tns_quant(L, lane, f, G.maxOrder, G.obits_off, code);
+        SUB(23);
         const int ord = uni(L.isc[I_TNS_ORD0 + f]);
         const int fstart = f ? G.start1 : G.start0, fstop = f ? G.stop1 : G.stop0;
         if (ord > 0) tns_lattice(L, lane, fstart - 1, fstop - fstart + 1, ord);
+        SUB(24);
     }
     if (lane == 0) { L.isc[I_TNS_NF] = G.numfilters; L.isc[I_TNS_BITS] = bits; }
     LSYNC();
@@ -1438,13 +1488,15 @@ __device__ __forceinline__ bool gain_probe(float thr7, float thr50, const float*
     const float fc = (float)cand;
     /* one step of R/estimate_global_gain.c:103-121, branch-free.  All four outcomes have the form (float)(((double)ener + X) + Y):
      * unchanged (0, 0); + 2.7*1.4 (c, 0); + 2t - 50*1.4 (2t, -70); float ener + t == (float)((double)ener + (double)t) because a
-     * double holds more than 2*24+2 bits (double rounding is innocuous).  X and Y are selected off the serial chain, which is
-     * then cvt - add - add - cvt. */
+     * double holds more than 2*24+2 bits (double rounding is innocuous).  X (a float: 0, t or 2t) and Y (0, c_lo or c_hi) are
+     * selected off the serial chain, which is then cvt - add - add - cvt; double-precision instructions cost twice a float one, so
+     * as much of the selection as possible happens in float. */
     const double c_lo = (2.7) * (28.0 / 20.0), c_hi = -((50.0) * (28.0 / 20.0));
-#define GSTEP(ev) do { const float t = (ev) - fc; const bool lo = t < thr7, hi = t > thr50; const double dt = (double)t; \
-        const double x_hi = opaque_d(hi ? dt + dt : dt), x_lo = opaque_d(iszero ? 0.0 : c_lo); \
-        const double X = lo ? x_lo : x_hi, Y = opaque_d((hi && !lo) ? c_hi : 0.0); \
-        ener = (float)(((double)ener + X) + Y); iszero = iszero && lo; } while (0)
+#define GSTEP(ev) do { const float t = (ev) - fc; const bool lo = t < thr7, hi = t > thr50; \
+        const float x_hi = opaque(hi ? t + t : t), xf = opaque(lo ? 0.0f : x_hi);            /* 2t is exact in float */ \
+        const double y_lo = opaque_d(iszero ? 0.0 : c_lo), y_hi = opaque_d(hi ? c_hi : 0.0); \
+        const double Y = opaque_d(lo ? y_lo : y_hi); \
+        ener = (float)(((double)ener + (double)xf) + Y); iszero = iszero && lo; } while (0)
     int j = nq - 1;
     for (; j >= 3; j -= 4) { const float v0 = en[j], v1 = en[j - 1], v2 = en[j - 2], v3 = en[j - 3]; GSTEP(v0); GSTEP(v1); GSTEP(v2); GSTEP(v3); }
     for (; j >= 0; j--) GSTEP(en[j]);
@@ -1543,6 +1595,7 @@ STAGE void st_quantize(const lc3d_plan* __restrict__ P, const lc3d_chan* __restr
     const float offs = PI(hrmode) ? 0.5f : 0.375f;
     const float gain = unif(L.fsc[F_GAIN]);
     int* xq = XQ(L); uint32_t* cdw = CDW(L);
+    SUB_BEGIN();
     for (int i = lane; i < nt; i += WAVE) {
         const float x = L.A[i];
         const int sg = x > 0 ? 1 : x < 0 ? -1 : 0;
@@ -1559,6 +1612,7 @@ STAGE void st_quantize(const lc3d_plan* __restrict__ P, const lc3d_chan* __restr
     const int ntup = (lastnz + 1) >> 1;
     int lastnz2 = mode < 0 ? lastnz + 1 : 2;
     int nbits2 = 0, base = 0, nlsb = 0, ct1 = 0, ct2 = 0;
+    SUB(28);
     for (int c0 = 0; c0 < ntup; c0 += WAVE) {
         const int p = c0 + lane; const bool act = p < ntup;
         const int x0 = act ? xq[2 * p] : 0, x1 = act ? xq[2 * p + 1] : 0;
@@ -1567,36 +1621,51 @@ STAGE void st_quantize(const lc3d_plan* __restrict__ P, const lc3d_chan* __restr
         const int af = a0 >> nsh, bf = b0 >> nsh;
         const int lev1 = imin(nsh, 3), levm = lev1 - 1;
         const int tval = levm <= 0 ? 1 + (af + bf) * (levm + 2) : 13 + levm;
-        int t1 = __shfl_up(tval, 1), t2 = __shfl_up(tval, 2);
-        if (lane == 0) { t1 = ct1; t2 = ct2; } else if (lane == 1) t2 = ct1;
+        /* context = the two previous tuples' values: wave_shr:1 hands lane 0 the carry-in of the previous pass */
+        const int t1 = dpp_i<DPP_WSHR1>(ct1, tval), t2 = dpp_i<DPP_WSHR1>(ct2, t1);
         int tin = 16 * (t2 & 15) + t1 + rate;
         if (2 * p > nt / 2) tin += 256;
         const int maxlev = mx == 0 ? -1 : flog2f_int((unsigned)imax(mx, 3)) - 1;
         int bits = 0, lsbc = 0;
-        if (act) {
-            if (mode <= 0) bits += (imin(a0, 1) + imin(b0, 1)) * 2048;
-            for (int lev = 0; lev < nsh; lev++) {
-                const int pki = lc3t_ac_ctx_lut[tin + imin(lev, 3) * 1024];
-                bits += lc3t_ac_bits[pki * 17 + 16];
-                if (lev == 0 && mode > 0) lsbc += 2; else bits += 2 * 2048;
+        {
+            /* models of the level classes 0..3 (class = min(level, 3)): all table reads of a pass are issued together, and only
+             * for classes some lane reaches.  Escape levels >= 3 share class 3, so their cost is a multiple of one entry. */
+            const int cls_f = imin(imax(maxlev, 0), 3);            /* class of the final symbol in the coder (R/ari_codec.c:723-727) */
+            const int need = act ? imax(lev1, cls_f) : -1;
+            int pk0 = 0, pk1 = 0, pk2c = 0, pk3 = 0, e0 = 0, e1 = 0, e2 = 0, e3 = 0;
+            if (need >= 0) pk0 = lc3t_ac_ctx_lut[tin];
+            const bool any1 = __ballot(need >= 1) != 0, any2 = __ballot(need >= 2) != 0;
+            if (any1) { if (need >= 1) pk1 = lc3t_ac_ctx_lut[tin + 1024]; }
+            if (any2) { if (need >= 2) pk2c = lc3t_ac_ctx_lut[tin + 2048]; if (need >= 3) pk3 = lc3t_ac_ctx_lut[tin + 3072]; }
+            if (any1) { if (nsh >= 1 && act) e0 = lc3t_ac_bits[pk0 * 17 + 16]; }
+            if (any2) { if (nsh >= 2 && act) e1 = lc3t_ac_bits[pk1 * 17 + 16];
+                        if (nsh >= 3 && act) e2 = lc3t_ac_bits[pk2c * 17 + 16];
+                        if (nsh >= 4 && act) e3 = lc3t_ac_bits[pk3 * 17 + 16]; }
+            const int sym = af + 4 * bf;
+            const int pkf = lev1 == 0 ? pk0 : lev1 == 1 ? pk1 : lev1 == 2 ? pk2c : pk3;
+            const int bsym = act ? lc3t_ac_bits[pkf * 17 + sym] : 0;
+            if (act) {
+                if (mode <= 0) bits += (imin(a0, 1) + imin(b0, 1)) * 2048;
+                bits += e0 + e1 + e2 + e3 * (nsh - 3);
+                if (mode > 0) { if (nsh > 0) { lsbc += 2; bits += 2 * 2048 * (nsh - 1); } } else bits += 2 * 2048 * nsh;
+                bits += bsym;
+                if (mode > 0) {
+                    int am = a0, bm = b0;
+                    if (lev1 > 0) { am >>= 1; bm >>= 1; if (am == 0 && x0 != 0) lsbc++; if (bm == 0 && x1 != 0) lsbc++; }
+                    bits += (imin(am, 1) + imin(bm, 1)) * 2048;
+                }
+                const int pkc = cls_f == 0 ? pk0 : cls_f == 1 ? pk1 : cls_f == 2 ? pk2c : pk3;
+                cdw[p] = (uint32_t)tin | ((uint32_t)(maxlev + 1) << 10) | ((uint32_t)pkc << 16) | ((uint32_t)sym << 22);
             }
-            const int pki = lc3t_ac_ctx_lut[tin + lev1 * 1024], sym = af + 4 * bf;
-            bits += lc3t_ac_bits[pki * 17 + sym];
-            if (mode > 0) {
-                int am = a0, bm = b0;
-                if (lev1 > 0) { am >>= 1; bm >>= 1; if (am == 0 && x0 != 0) lsbc++; if (bm == 0 && x1 != 0) lsbc++; }
-                bits += (imin(am, 1) + imin(bm, 1)) * 2048;
-            }
-            const int pk2 = lc3t_ac_ctx_lut[tin + imin(imax(maxlev, 0), 3) * 1024];     /* model of the final symbol (R/ari_codec.c:723-727) */
-            cdw[p] = (uint32_t)tin | ((uint32_t)(maxlev + 1) << 10) | ((uint32_t)pk2 << 16) | ((uint32_t)sym << 22);
         }
         const int incl = wave_incl_scan_i(bits, lane) + base;
         const unsigned long long ok = __ballot(act && mode >= 0 && (a0 != 0 || b0 != 0) && incl <= target * 2048);
-        if (ok) { const int hl = 63 - __clzll((long long)ok); lastnz2 = 2 * (c0 + hl) + 2; nbits2 = uni(__shfl(incl, hl)); }
-        base = uni(__shfl(incl, 63));
-        nlsb += uni(wave_sum_i(lsbc));
-        ct2 = uni(__shfl(tval, 62)); ct1 = uni(__shfl(tval, 63));
+        if (ok) { const int hl = 63 - __clzll((long long)ok); lastnz2 = 2 * (c0 + hl) + 2; nbits2 = __builtin_amdgcn_readlane(incl, hl); }
+        base = __builtin_amdgcn_readlane(incl, 63);
+        if (mode > 0) nlsb += wave_sum_i(lsbc);
+        ct2 = __builtin_amdgcn_readlane(tval, 62); ct1 = __builtin_amdgcn_readlane(tval, 63);
     }
+    SUB(29);
     int nbits = (base + 2047) >> 11;
     if (mode >= 0) nbits2 = (nbits2 + 2047) >> 11; else nbits2 = nbits;
     if (mode > 0) { nbits += nlsb; nbits2 += nlsb; }
@@ -1638,22 +1707,39 @@ STAGE void st_noise_factor(const lc3d_plan* __restrict__ P, WaveLds& L, int lane
     const int width = dms == 100 ? 8 : 4, first = dms == 100 ? 24 : dms == 50 ? 12 : 6, hw = (width - 2) / 2;
     const float gg = unif(L.fsc[F_GAIN]);
     const int* xq = XQ(L);
-    int nz = 0, sumz = 0;
-    unsigned long long zm[8];                       /* zero-line masks of up to 8 chunks of 64 bins (bw_bin <= 480) */
+    SUB_BEGIN();
+    int nz = 0;
+    /* nzb[c]: non-zero lines among bins 64c .. 64c+63 below the bandwidth cut-off (R/noise_factor.c:47-60 looks at xq only there) */
+    unsigned long long nzb[10];
 #pragma unroll
     for (int c = 0; c < 8; c++) {
-        const int k = first + 64 * c + lane;
-        bool allz = false;
-        if (k < bw_bin) {
-            allz = true;
-            const int lo = k - hw, hi = imin(bw_bin - 1, k + hw);
-            for (int i = lo; i <= hi; i++) if (xq[i] != 0) allz = false;
-        }
-        zm[c] = __ballot(allz);
-        nz += __popcll(zm[c]);
-        sumz += uni(wave_sum_i(allz ? k + 1 : 0));
+        const int k = 64 * c + lane;
+        const int q = xq[k];                        /* k < 512: in bounds of the LDS slice; lines >= bw_bin are masked */
+        nzb[c] = __ballot(k < bw_bin && q != 0);
     }
+    nzb[8] = nzb[9] = 0;
+    /* zm[c]: zero-line masks (lines whose +-hw neighbourhood is all zero) of chunk c = bins first + 64c .. +63.  The 2hw+1 window
+     * bits of lane l start at bit (first - hw) + 64c + l of the 512-bit mask: a uniform 128-bit pre-shift, then a per-lane shift. */
+    unsigned long long zm[8];
+    const int o = first - hw; const unsigned wm = (1u << (2 * hw + 1)) - 1u;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        zm[c] = 0;
+        if (first + 64 * c < bw_bin) {
+            const unsigned long long lo64 = (nzb[c] >> o) | (nzb[c + 1] << (64 - o)), hi64 = (nzb[c + 1] >> o) | (nzb[c + 2] << (64 - o));
+            const unsigned w = (unsigned)(lo64 >> lane) | (unsigned)((hi64 << 1) << (63 - lane));
+            zm[c] = __ballot(first + 64 * c + lane < bw_bin && (w & wm) == 0);
+            nz += __popcll(zm[c]);
+        }
+    }
+    SUB(31);
+    int sumz = nz;                                  /* only its sign matters unless the spectrum is split (below) */
     const bool split = CI(nbytes) <= 20 && dms == 100 && nz > 0;
+    if (split) {
+        sumz = 0;
+#pragma unroll
+        for (int c = 0; c < 8; c++) sumz += wave_sum_i(((zm[c] >> lane) & 1ull) ? first + 64 * c + lane + 1 : 0);
+    }
     const int msplit = split ? sumz / nz : 0x7fffffff;
     float m1 = 0, m2 = 0; int j1 = 0;
     if (!split) {
@@ -1696,6 +1782,7 @@ STAGE void st_noise_factor(const lc3d_plan* __restrict__ P, WaveLds& L, int lane
     { const float t = idx > 0 ? idx : 0; idx = t < 7 ? t : 7; }
     if (lane == 0) L.isc[I_FACNS] = (int)idx;
     LSYNC();
+    SUB(32);
 }
 
 /* ---- residual coding R/residual_coding.c:13-75 ----
@@ -1804,7 +1891,7 @@ __device__ __forceinline__ void big_add(unsigned* big, unsigned v, int s)
     while (add) { old = atomicAdd(&big[w], add); add = (old + add) < add ? 1u : 0u; w++; }
 }
 
-struct AriSt { int range, s8; int a0; };         /* range, 8 * shifts so far, sum of the c_j added since the last shift */
+struct AriSt { int range, s8; int pa; };         /* range, 8 * shifts so far; pa (per lane): the c_j this lane added since the last shift */
 
 /* code up to 64 symbols: lane j < cnt holds symbol j as cum | freq << 16 */
 __device__ __forceinline__ void ari_chunk(AriSt& w, unsigned* big, int lane, unsigned vsym, int cnt)
@@ -1828,7 +1915,7 @@ __device__ __forceinline__ void ari_chunk(AriSt& w, unsigned* big, int lane, uns
     const int sk8 = w.s8 + incl - n8, s8_end = w.s8 + tot;
     const unsigned c = on ? (unsigned)(vr * vcum) : 0u;
     if (c) big_add(big, c, sk8 >> 3);
-    w.a0 = (tot == 0 ? w.a0 : 0) + wave_sum_i(sk8 == s8_end ? (int)c : 0);
+    w.pa = (tot == 0 ? w.pa : 0) + (sk8 == s8_end ? (int)c : 0);
     w.s8 = s8_end;
 }
 
@@ -1847,48 +1934,43 @@ STAGE void st_bitstream(const lc3d_plan* __restrict__ P, const lc3d_chan* __rest
     const int lastnz = uni(isc[I_LASTNZ]), lsbMode = uni(isc[I_LSB]), nres = uni(isc[I_NRES]);
     const int bw_idx = uni(isc[I_BW]), gg = uni(isc[I_GG]), fac_ns = uni(isc[I_FACNS]);
     const int* xq = XQ(L); const uint32_t* cdw = CDW(L); uint8_t* resb = RESB(L);
-    /* ---- side information: fields appended LSB-first into a 128-bit accumulator (uniform), R/enc_entropy.c:25-87 ---- */
-    unsigned long long slo = 0, shi = 0; int Q = 0;
-#define SIDE(val_, n_) do { unsigned long long v_ = (unsigned long long)(unsigned)(val_) & (((n_) >= 32) ? 0xffffffffull : ((1ull << (n_)) - 1ull)); \
-        if (Q < 64) { slo |= v_ << Q; if (Q + (n_) > 64) shi |= v_ >> (64 - Q); } else shi |= v_ << (Q - 64); Q += (n_); } while (0)
+    /* ---- side information, R/enc_entropy.c:25-87: lane i forms field i (value, width); a prefix sum places it ---- */
+    int Q;
     {
-        const int gain_msb_bits[4] = {1, 1, 2, 2}, gain_lsb_bits[4] = {0, 1, 0, 1};
-        if (PI(bw_bits) > 0) SIDE(bw_idx, PI(bw_bits));
-        SIDE(lastnz / 2 - 1, ilog2((unsigned)(PI(ylen) / 2 - 1)) + 1);
-        SIDE(lsbMode, 1);
-        SIDE(gg, 8);
-        for (int i = 0; i < nfilt; i++) SIDE(imin(1, isc[I_TNS_ORD0 + i]), 1);
-        SIDE(isc[I_LTPF0], 1);
-        SIDE(isc[I_SCF0], 5); SIDE(isc[I_SCF1], 5);
-        const int s2 = isc[I_SCF2], s3 = isc[I_SCF3];
-        const int sub_msb = s2 / 2, sub_lsb = s2 & 1;
-        SIDE(sub_msb, 1);
-        const int g_msb = s3 >> gain_lsb_bits[s2], g_lsb = s3 & 1;
-        SIDE(g_msb, gain_msb_bits[s2]);
-        SIDE(isc[I_SCF4], 1);
-        if (sub_msb == 0) {
-            int t = sub_lsb == 0 ? isc[I_SCF6] + 2 : g_lsb;
-            t = t * 2390004 + isc[I_SCF5];
-            SIDE(t, 25);
-        } else {
-            int t = isc[I_SCF5];
-            if (sub_lsb != 0) t = 2 * t + g_lsb + 15158272;
-            SIDE(t, 24);
-        }
-        if (isc[I_LTPF0] == 1) { SIDE(isc[I_LTPF1], 1); SIDE(isc[I_LTPF2], 9); }
-        SIDE(fac_ns, 3);
-    }
-#undef SIDE
-    Q = uni(Q);
-    if (lane < 4) {
-        const unsigned piece = lane == 0 ? (unsigned)slo : lane == 1 ? (unsigned)(slo >> 32) : lane == 2 ? (unsigned)shi : (unsigned)(shi >> 32);
-        or_bits_back(bytes, nbytes, 32 * lane, piece, imin(32, Q - 32 * lane));
+        const int s2 = isc[I_SCF2], s3 = isc[I_SCF3], s5 = isc[I_SCF5], s6 = isc[I_SCF6], ltpf0 = isc[I_LTPF0];
+        const int sub_msb = s2 >> 1, sub_lsb = s2 & 1, g_lsb = s3 & 1;
+        int joint, jbits;
+        if (sub_msb == 0) { joint = (sub_lsb == 0 ? s6 + 2 : g_lsb) * 2390004 + s5; jbits = 25; }
+        else { joint = sub_lsb != 0 ? 2 * s5 + g_lsb + 15158272 : s5; jbits = 24; }
+        const int o0 = isc[I_TNS_ORD0], o1 = isc[I_TNS_ORD1], sc0 = isc[I_SCF0], sc1 = isc[I_SCF1], sc4 = isc[I_SCF4], lt1 = isc[I_LTPF1], lt2 = isc[I_LTPF2];
+        int v = 0, n = 0;
+#define FIELD(k_, val_, width_) do { const bool m_ = lane == (k_); v = m_ ? (val_) : v; n = m_ ? (width_) : n; } while (0)
+        FIELD(0, bw_idx, PI(bw_bits));
+        FIELD(1, lastnz / 2 - 1, ilog2((unsigned)(PI(ylen) / 2 - 1)) + 1);
+        FIELD(2, lsbMode, 1);
+        FIELD(3, gg, 8);
+        FIELD(4, imin(1, o0), nfilt > 0 ? 1 : 0);
+        FIELD(5, imin(1, o1), nfilt > 1 ? 1 : 0);
+        FIELD(6, ltpf0, 1);
+        FIELD(7, sc0, 5);
+        FIELD(8, sc1, 5);
+        FIELD(9, sub_msb, 1);
+        FIELD(10, s3 >> (s2 & 1), 1 + sub_msb);                        /* gain msbs: 1, 1, 2, 2 bits for sub-modes 0..3 */
+        FIELD(11, sc4, 1);
+        FIELD(12, joint, jbits);
+        FIELD(13, lt1, ltpf0 == 1 ? 1 : 0);
+        FIELD(14, lt2, ltpf0 == 1 ? 9 : 0);
+        FIELD(15, fac_ns, 3);
+#undef FIELD
+        const int incl = wave_incl_scan_i(n, lane);
+        or_bits_back(bytes, nbytes, incl - n, (unsigned long long)(unsigned)v, n);
+        Q = __builtin_amdgcn_readlane(incl, 63);
     }
     if (lane == 0) { isc[I_BP_SIDE] = nbytes - 1 - (Q >> 3); isc[I_MASK_SIDE] = 1 << (Q & 7); }
     SUB(15);
 
     /* ---- range coder: TNS symbols (order, then coefficients, per filter) ---- */
-    AriSt w; w.range = 0xFFFFFF; w.s8 = 0; w.a0 = 0;
+    AriSt w; w.range = 0xFFFFFF; w.s8 = 0; w.pa = 0;
     {
         const int ord0 = nfilt > 0 ? uni(isc[I_TNS_ORD0]) : 0, ord1 = nfilt > 1 ? uni(isc[I_TNS_ORD1]) : 0;
         const int n0 = ord0 > 0 ? ord0 + 1 : 0, n1 = ord1 > 0 ? ord1 + 1 : 0, nt = n0 + n1;
@@ -1995,7 +2077,8 @@ STAGE void st_bitstream(const lc3d_plan* __restrict__ P, const lc3d_chan* __rest
     const uint8_t* bb = (const uint8_t*)big;
     const int low = (bb[BIGB - 1 - S] << 16) | (bb[BIGB - 2 - S] << 8) | bb[BIGB - 3 - S];
     /* carry flag of the reference at this point: did the adds since the last shift leave the 24-bit window? */
-    const int c_pending = (int)(((((unsigned)low - (unsigned)w.a0) & 0xFFFFFFu) + (unsigned)w.a0) >> 24);
+    const unsigned a0 = (unsigned)wave_sum_i(w.pa);       /* sum of the c_j added at the final shift count: < 2^25 */
+    const int c_pending = (int)(((((unsigned)low - a0) & 0xFFFFFFu) + a0) >> 24);
     int bits = 24 - flog2f_int((unsigned)w.range);
     int mask = 0xFFFFFF >> bits, val = low + mask; const int over1 = val >> 24;
     val &= 0xFFFFFF;

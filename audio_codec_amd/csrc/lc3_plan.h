@@ -35,6 +35,7 @@ typedef struct {
     float   sns_preemph[64];
     float   gain_est[LC3D_GAIN_TAB];               /* powf(10, (k)/28.0)  (double division) */
     float   gain_adj[LC3D_GAIN_TAB];               /* powf(10, (float)k/28) (float division) */
+    float   rs_taps[240];                          /* 12.8 kHz resampler low-pass, phase-major: [start][m] = lp[239 - start - m*stride] (R/resamp12k8.c:48-57) */
     double  idct_cos[256];
     uint8_t band_of_bin[LC3D_MAX_N];
     uint8_t pfa_src[360];       /* N/2 = 120 prime-factor DFT: gather maps of the 8-, 3- and 5-point stages */

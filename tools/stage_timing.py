@@ -20,7 +20,10 @@ SUBS = {0: "resample: FIR", 1: "resample: biquad products", 2: "resample: biquad
         4: "sns_vq: stage 1", 5: "sns_vq: DCT-II", 6: "sns_vq: pulse searches", 7: "sns_vq: gains + IDCT", 8: "sns_vq: errors + select",
         9: "sns_vq: MPVQ index", 10: "gain_est: x_max / regulariser", 11: "gain_est: band energies (log10)", 12: "gain_est: probe (6 levels)",
         13: "gain_est: probe (last 2)", 14: "gain_est: tail", 15: "bitstream: clear + side info", 16: "bitstream: TNS symbols",
-        17: "bitstream: tuple prep (parallel)", 18: "bitstream: range coder (serial)", 19: "bitstream: residual bits", 20: "bitstream: finalise"}
+        17: "bitstream: tuple prep (parallel)", 18: "bitstream: range coder (serial)", 19: "bitstream: residual bits", 20: "bitstream: finalise",
+        21: "tns: sums", 22: "tns: levinson (+weight)", 23: "tns: rc quant", 24: "tns: lattice", 25: "olpa: decimate + slide",
+        26: "olpa: autocorr + argmax", 27: "olpa: normcorr + decision", 28: "quant: quantise + lastnz", 29: "quant: bit estimate passes",
+        31: "noise: zero-line masks", 32: "noise: sums"}
 accall = np.zeros(64)
 for s in range(B):
     accall += np.frombuffer(tr[s * T].tobytes()[:64 * 8], dtype=np.int64)
