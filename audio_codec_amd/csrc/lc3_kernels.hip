@@ -67,6 +67,7 @@ struct __attribute__((aligned(16))) WaveLds {
     long long tacc[NSTAGE];
 #endif
 };
+static_assert(offsetof(WaveLds, A) % 16 == 0 && (offsetof(WaveLds, sm) + 242 * 4) % 16 == 0 && offsetof(WaveLds, xbuf) == 0, "16-byte aligned LDS rows");
 #define PI(f) uni(L.pc[offsetof(lc3d_plan, f) / 4])
 #define PF(f) __int_as_float(uni(L.pc[offsetof(lc3d_plan, f) / 4]))
 #define CI(f) uni(L.cc[offsetof(lc3d_chan, f) / 4])
@@ -419,19 +420,40 @@ STAGE void st_resample(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
 
 /* normalised correlation at lag T over acf <= 64 samples (R/olpa.c:104-114): the three serial float sums run in all lanes,
  * the products come back from LDS scratch (A) with uniform-address reads */
-__device__ __forceinline__ float olpa_normcorr(WaveLds& L, const float* s6, int acf, int T, int lane, float eps)
+/* Serial float sums, one per lane: lane s < nsums adds base[s*stride + 0 .. count-1] in index order (the reference's order) and
+ * keeps the total.  A dependent add issues every ~6 cycles whether one lane or all of them run it, so independent sums belong in
+ * different lanes rather than in one uniform loop.  Rows are 16-byte aligned and padded to a multiple of 4 readable floats. */
+__device__ __forceinline__ float lane_serial_sum(const float* base, int stride, int nsums, int count, int lane)
+{
+    const float4* p = (const float4*)(base + (lane < nsums ? lane : 0) * stride);
+    float acc = 0;
+    int i = 0;
+    for (; i + 8 <= count; i += 8) {
+        const float4 u = p[i >> 2], v = p[(i >> 2) + 1];
+        acc += u.x; acc += u.y; acc += u.z; acc += u.w; acc += v.x; acc += v.y; acc += v.z; acc += v.w;
+    }
+    for (; i < count; i += 4) {                      /* tail: terms past `count` are skipped by selects, not by branches */
+        const float4 u = p[i >> 2];
+        acc += u.x; acc += (i + 1 < count) ? u.y : 0.0f; acc += (i + 2 < count) ? u.z : 0.0f; acc += (i + 3 < count) ? u.w : 0.0f;
+    }
+    return acc;
+}
+
+/* normalised correlations at lags T_a and T_b over acf <= 64 samples (R/olpa.c:104-114), both at once: five serial sums
+ * (ab_a, bb_a, aa, ab_b, bb_b) in five lanes, products parked in LDS scratch (A) */
+__device__ __forceinline__ void olpa_normcorr2(WaveLds& L, const float* s6, int acf, int Ta, int Tb, int lane, float eps, float& nca, float& ncb)
 {
     float* pr = L.A;
-    if (lane < acf) { const float a = s6[lane], b = s6[lane - T]; pr[lane] = a * b; pr[64 + lane] = b * b; pr[128 + lane] = a * a; }
+    if (lane < acf) {
+        const float a = s6[lane], ba = s6[lane - Ta], bb = s6[lane - Tb];
+        pr[lane] = a * ba; pr[64 + lane] = ba * ba; pr[128 + lane] = a * a; pr[192 + lane] = a * bb; pr[256 + lane] = bb * bb;
+    }
     LSYNC();
-    float s0 = 0, s1 = 0, s2 = 0;
-#pragma unroll 8
-    for (int i = 0; i < acf; i++) { s0 += pr[i]; s1 += pr[64 + i]; s2 += pr[128 + i]; }
+    const float acc = lane_serial_sum(pr, 64, 5, acf, lane);
     LSYNC();
-    s1 = s1 * s2;
-    s1 = sqrtf(s1) + eps;
-    const float nc = s0 / s1;
-    return 0 > nc ? 0 : nc;
+    const float s_aa = rl_f(acc, 2);
+    { float s1 = rl_f(acc, 1) * s_aa; s1 = sqrtf(s1) + eps; const float nc = rl_f(acc, 0) / s1; nca = 0 > nc ? 0 : nc; }
+    { float s1 = rl_f(acc, 4) * s_aa; s1 = sqrtf(s1) + eps; const float nc = rl_f(acc, 3) / s1; ncb = 0 > nc ? 0 : nc; }
 }
 
 /* ---- open-loop pitch: R/olpa.c:52-143 ---- */
@@ -474,16 +496,14 @@ STAGE void st_olpa(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
     int T0 = uni(besti) + 17;
     LSYNC();
     SUB(26);
-    float nc = olpa_normcorr(L, s6, acf, T0, lane, PF(c_1em5_a));
     const int old = uni(L.isc[I_OLPA_PITCH]);
     const int lo = imax(17, old - 4), hi = imin(114, old + 4), cnt = hi - lo + 1;
     float v = (lane & 15) < cnt ? R0[lo - 17 + (lane & 15)] : -INFINITY; int vi = lane & 15;
     wave_argmax_first<16>(v, vi);
     const int T02 = uni(vi) + lo;
-    if (T02 != T0) {
-        const float nc2 = olpa_normcorr(L, s6, acf, T02, lane, PF(c_1em5_a));
-        if ((double)nc2 > ((double)nc * 0.85)) { T0 = T02; nc = nc2; }
-    }
+    float nc, nc2;
+    olpa_normcorr2(L, s6, acf, T0, T02, lane, PF(c_1em5_a), nc, nc2);
+    if (T02 != T0 && (double)nc2 > ((double)nc * 0.85)) { T0 = T02; nc = nc2; }
     if (lane == 0) { L.isc[I_OLPA_PITCH] = T0; L.isc[I_T0] = (int)(T0 * 2.0); L.fsc[F_NC] = nc; }
     LSYNC();
     SUB(27);
@@ -513,8 +533,8 @@ STAGE void st_ltpf(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict_
                 if (j < acf) { const float a = x[j], b = x[j - t_min]; pr[j] = a * a; pr[128 + j] = b * b; }
             }
             LSYNC();
-#pragma unroll 8
-            for (int i = 0; i < acf; i++) { sum1 += pr[i]; sum2 += pr[128 + i]; }
+            const float acc = lane_serial_sum(pr, 128, 2, acf, lane);
+            sum1 = rl_f(acc, 0); sum2 = rl_f(acc, 1);
             LSYNC();
         }
         float* cor = &L.sm[SM_MISC];           /* up to 17 */
@@ -578,8 +598,8 @@ STAGE void st_ltpf(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict_
                 }
             }
             LSYNC();
-#pragma unroll 8
-            for (int i = 0; i < acf; i++) { a += pq[i]; b += pq[128 + i]; c += pq[256 + i]; }
+            const float acc = lane_serial_sum(pq, 128, 3, acf, lane);
+            a = rl_f(acc, 0); b = rl_f(acc, 1); c = rl_f(acc, 2);
         }
         b = sqrtf(b * c) + PF(c_1em5_b);
         norm_corr = a / b;
@@ -1613,58 +1633,67 @@ STAGE void st_quantize(const lc3d_plan* __restrict__ P, const lc3d_chan* __restr
     int lastnz2 = mode < 0 ? lastnz + 1 : 2;
     int nbits2 = 0, base = 0, nlsb = 0, ct1 = 0, ct2 = 0;
     SUB(28);
+    /* Two dependent rounds of table reads per pass (context LUT -> bit costs).  Pass p+1's quantised values, contexts and LUT
+     * reads are formed while pass p's bit costs are still in flight. */
+    int x0N = 0, x1N = 0, nshN = 0, lev1N = 0, maxlevN = 0, symN = 0, tinN = 0, clsN = 0, needN = -1, pk0N = 0, pk1N = 0, pk2N = 0, pk3N = 0;
+#define QPASS_HEAD(c0_) do { const int p_ = (c0_) + lane; const bool act_ = p_ < ntup; \
+        x0N = act_ ? xq[2 * p_] : 0; x1N = act_ ? xq[2 * p_ + 1] : 0; \
+        const int a_ = x0N < 0 ? -x0N : x0N, b_ = x1N < 0 ? -x1N : x1N, mx_ = imax(a_, b_); \
+        nshN = mx_ >= 4 ? ilog2((unsigned)mx_) - 1 : 0; \
+        const int af_ = a_ >> nshN, bf_ = b_ >> nshN; \
+        lev1N = imin(nshN, 3); const int levm_ = lev1N - 1; \
+        const int tval_ = levm_ <= 0 ? 1 + (af_ + bf_) * (levm_ + 2) : 13 + levm_; \
+        /* context = the two previous tuples' values: wave_shr:1 hands lane 0 the carry-in of the previous pass */ \
+        const int t1_ = dpp_i<DPP_WSHR1>(ct1, tval_), t2_ = dpp_i<DPP_WSHR1>(ct2, t1_); \
+        tinN = 16 * (t2_ & 15) + t1_ + rate; if (2 * p_ > nt / 2) tinN += 256; \
+        maxlevN = mx_ == 0 ? -1 : flog2f_int((unsigned)imax(mx_, 3)) - 1; \
+        symN = af_ + 4 * bf_; \
+        clsN = imin(imax(maxlevN, 0), 3);             /* class of the final symbol in the coder (R/ari_codec.c:723-727) */ \
+        needN = act_ ? imax(lev1N, clsN) : -1; \
+        if (needN >= 0) pk0N = lc3t_ac_ctx_lut[tinN]; \
+        if (__ballot(needN >= 1)) { if (needN >= 1) pk1N = lc3t_ac_ctx_lut[tinN + 1024]; \
+            if (__ballot(needN >= 2)) { if (needN >= 2) pk2N = lc3t_ac_ctx_lut[tinN + 2048]; if (needN >= 3) pk3N = lc3t_ac_ctx_lut[tinN + 3072]; } } \
+        ct2 = __builtin_amdgcn_readlane(tval_, 62); ct1 = __builtin_amdgcn_readlane(tval_, 63); } while (0)
+    if (ntup > 0) QPASS_HEAD(0);
     for (int c0 = 0; c0 < ntup; c0 += WAVE) {
         const int p = c0 + lane; const bool act = p < ntup;
-        const int x0 = act ? xq[2 * p] : 0, x1 = act ? xq[2 * p + 1] : 0;
-        const int a0 = x0 < 0 ? -x0 : x0, b0 = x1 < 0 ? -x1 : x1, mx = imax(a0, b0);
-        const int nsh = mx >= 4 ? ilog2((unsigned)mx) - 1 : 0;
-        const int af = a0 >> nsh, bf = b0 >> nsh;
-        const int lev1 = imin(nsh, 3), levm = lev1 - 1;
-        const int tval = levm <= 0 ? 1 + (af + bf) * (levm + 2) : 13 + levm;
-        /* context = the two previous tuples' values: wave_shr:1 hands lane 0 the carry-in of the previous pass */
-        const int t1 = dpp_i<DPP_WSHR1>(ct1, tval), t2 = dpp_i<DPP_WSHR1>(ct2, t1);
-        int tin = 16 * (t2 & 15) + t1 + rate;
-        if (2 * p > nt / 2) tin += 256;
-        const int maxlev = mx == 0 ? -1 : flog2f_int((unsigned)imax(mx, 3)) - 1;
-        int bits = 0, lsbc = 0;
-        {
-            /* models of the level classes 0..3 (class = min(level, 3)): all table reads of a pass are issued together, and only
-             * for classes some lane reaches.  Escape levels >= 3 share class 3, so their cost is a multiple of one entry. */
-            const int cls_f = imin(imax(maxlev, 0), 3);            /* class of the final symbol in the coder (R/ari_codec.c:723-727) */
-            const int need = act ? imax(lev1, cls_f) : -1;
-            int pk0 = 0, pk1 = 0, pk2c = 0, pk3 = 0, e0 = 0, e1 = 0, e2 = 0, e3 = 0;
-            if (need >= 0) pk0 = lc3t_ac_ctx_lut[tin];
-            const bool any1 = __ballot(need >= 1) != 0, any2 = __ballot(need >= 2) != 0;
-            if (any1) { if (need >= 1) pk1 = lc3t_ac_ctx_lut[tin + 1024]; }
-            if (any2) { if (need >= 2) pk2c = lc3t_ac_ctx_lut[tin + 2048]; if (need >= 3) pk3 = lc3t_ac_ctx_lut[tin + 3072]; }
-            if (any1) { if (nsh >= 1 && act) e0 = lc3t_ac_bits[pk0 * 17 + 16]; }
-            if (any2) { if (nsh >= 2 && act) e1 = lc3t_ac_bits[pk1 * 17 + 16];
-                        if (nsh >= 3 && act) e2 = lc3t_ac_bits[pk2c * 17 + 16];
-                        if (nsh >= 4 && act) e3 = lc3t_ac_bits[pk3 * 17 + 16]; }
-            const int sym = af + 4 * bf;
-            const int pkf = lev1 == 0 ? pk0 : lev1 == 1 ? pk1 : lev1 == 2 ? pk2c : pk3;
-            const int bsym = act ? lc3t_ac_bits[pkf * 17 + sym] : 0;
-            if (act) {
-                if (mode <= 0) bits += (imin(a0, 1) + imin(b0, 1)) * 2048;
-                bits += e0 + e1 + e2 + e3 * (nsh - 3);
-                if (mode > 0) { if (nsh > 0) { lsbc += 2; bits += 2 * 2048 * (nsh - 1); } } else bits += 2 * 2048 * nsh;
-                bits += bsym;
-                if (mode > 0) {
-                    int am = a0, bm = b0;
-                    if (lev1 > 0) { am >>= 1; bm >>= 1; if (am == 0 && x0 != 0) lsbc++; if (bm == 0 && x1 != 0) lsbc++; }
-                    bits += (imin(am, 1) + imin(bm, 1)) * 2048;
-                }
-                const int pkc = cls_f == 0 ? pk0 : cls_f == 1 ? pk1 : cls_f == 2 ? pk2c : pk3;
-                cdw[p] = (uint32_t)tin | ((uint32_t)(maxlev + 1) << 10) | ((uint32_t)pkc << 16) | ((uint32_t)sym << 22);
+        const int x0 = x0N, x1 = x1N, nsh = nshN, lev1 = lev1N, maxlev = maxlevN, sym = symN, tin = tinN, cls_f = clsN, need = needN;
+        const int pk0 = pk0N, pk1 = pk1N, pk2c = pk2N, pk3 = pk3N;
+        const int a0 = x0 < 0 ? -x0 : x0, b0 = x1 < 0 ? -x1 : x1;
+        /* bit costs (1/2048 bit) of the escape symbols of classes 0..3 (levels >= 3 share class 3) and of the final symbol */
+        int e0 = 0, e1 = 0, e2 = 0, e3 = 0;
+        if (__ballot(need >= 1)) {
+            if (nsh >= 1 && act) e0 = lc3t_ac_bits[pk0 * 17 + 16];
+            if (__ballot(need >= 2)) {
+                if (nsh >= 2 && act) e1 = lc3t_ac_bits[pk1 * 17 + 16];
+                if (nsh >= 3 && act) e2 = lc3t_ac_bits[pk2c * 17 + 16];
+                if (nsh >= 4 && act) e3 = lc3t_ac_bits[pk3 * 17 + 16];
             }
+        }
+        const int pkf = lev1 == 0 ? pk0 : lev1 == 1 ? pk1 : lev1 == 2 ? pk2c : pk3;
+        const int bsym = act ? lc3t_ac_bits[pkf * 17 + sym] : 0;
+        if (c0 + WAVE < ntup) QPASS_HEAD(c0 + WAVE);
+        int bits = 0, lsbc = 0;
+        if (act) {
+            if (mode <= 0) bits += (imin(a0, 1) + imin(b0, 1)) * 2048;
+            bits += e0 + e1 + e2 + e3 * (nsh - 3);
+            if (mode > 0) { if (nsh > 0) { lsbc += 2; bits += 2 * 2048 * (nsh - 1); } } else bits += 2 * 2048 * nsh;
+            bits += bsym;
+            if (mode > 0) {
+                int am = a0, bm = b0;
+                if (lev1 > 0) { am >>= 1; bm >>= 1; if (am == 0 && x0 != 0) lsbc++; if (bm == 0 && x1 != 0) lsbc++; }
+                bits += (imin(am, 1) + imin(bm, 1)) * 2048;
+            }
+            const int pkc = cls_f == 0 ? pk0 : cls_f == 1 ? pk1 : cls_f == 2 ? pk2c : pk3;
+            cdw[p] = (uint32_t)tin | ((uint32_t)(maxlev + 1) << 10) | ((uint32_t)pkc << 16) | ((uint32_t)sym << 22);
         }
         const int incl = wave_incl_scan_i(bits, lane) + base;
         const unsigned long long ok = __ballot(act && mode >= 0 && (a0 != 0 || b0 != 0) && incl <= target * 2048);
         if (ok) { const int hl = 63 - __clzll((long long)ok); lastnz2 = 2 * (c0 + hl) + 2; nbits2 = __builtin_amdgcn_readlane(incl, hl); }
         base = __builtin_amdgcn_readlane(incl, 63);
         if (mode > 0) nlsb += wave_sum_i(lsbc);
-        ct2 = __builtin_amdgcn_readlane(tval, 62); ct1 = __builtin_amdgcn_readlane(tval, 63);
     }
+#undef QPASS_HEAD
     SUB(29);
     int nbits = (base + 2047) >> 11;
     if (mode >= 0) nbits2 = (nbits2 + 2047) >> 11; else nbits2 = nbits;
@@ -1745,7 +1774,7 @@ STAGE void st_noise_factor(const lc3d_plan* __restrict__ P, WaveLds& L, int lane
     if (!split) {
         /* common case: one serial sum over all zero lines.  They are compacted (in bin order) into LDS scratch three chunks
          * at a time and summed with uniform-address reads. */
-        float* lst = &L.sm[240];                    /* 308 free words: the residual-bit area is not in use yet */
+        float* lst = &L.sm[242];                    /* 306 free words (16-byte aligned): the residual-bit area is not in use yet */
         j1 = nz;
 #pragma unroll
         for (int g = 0; g < 8; g += 3) {
@@ -1757,9 +1786,12 @@ STAGE void st_noise_factor(const lc3d_plan* __restrict__ P, WaveLds& L, int lane
                 if ((m >> lane) & 1ull) lst[cntg + __popcll(m & ((1ull << lane) - 1ull))] = fabsf(L.A[k] / gg);
                 cntg += __popcll(m);
             }
+            if (lane < 8) lst[cntg + lane] = 0.0f;  /* pad to a whole block: adding +0 is exact */
             LSYNC();
-#pragma unroll 8
-            for (int j = 0; j < cntg; j++) m1 += lst[j];
+            for (int j = 0; j < cntg; j += 8) {
+                const float4 u = *(const float4*)&lst[j], v = *(const float4*)&lst[j + 4];
+                m1 += u.x; m1 += u.y; m1 += u.z; m1 += u.w; m1 += v.x; m1 += v.y; m1 += v.z; m1 += v.w;
+            }
             LSYNC();
         }
     } else
@@ -1829,24 +1861,19 @@ STAGE void st_residual(const lc3d_plan* __restrict__ P, WaveLds& L, int lane, in
  * (readlane -> scalar registers), its output bytes are collected with writelane and stored 64 at a time. ---- */
 
 /* OR the n (<= 56) low bits of v into the backward stream at bit position q (bit 0 = LSB of the last frame byte) */
-__device__ __forceinline__ void or_bits_back(uint8_t* bytes, int nbytes, int q, unsigned long long v, int n)
+/* The backward part of a frame (side information, escape LSBs, signs, residual bits) is written from the last byte towards the
+ * first, LSB first (write_bit_backward_fl, R/enc_entropy.c:101-115).  Seen from the end of the frame that is one little-endian
+ * bit string: backward bit q is bit (q & 31) of word q >> 5 of `rb`, whose byte j is frame byte nbytes-1-j.  OR n (<= 64) bits. */
+__device__ __forceinline__ void or_bits_back(unsigned* rb, int q, unsigned long long v, int n)
 {
     if (n <= 0) return;
     v &= (n >= 64) ? ~0ull : ((1ull << n) - 1ull);
-    const unsigned long long V = v << (q & 7);
-    const int A0 = nbytes - 1 - (q >> 3), w0 = A0 >> 2;
-    unsigned m0 = 0, m1 = 0, m2 = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const unsigned b = (unsigned)((V >> (8 * i)) & 0xffull);
-        const int A = A0 - i, d = w0 - (A >> 2);
-        const unsigned val = b << (8 * (A & 3));
-        if (d == 0) m0 |= val; else if (d == 1) m1 |= val; else m2 |= val;
-    }
-    unsigned* W = (unsigned*)bytes;
-    if (m0) atomicOr(&W[w0], m0);
-    if (m1) atomicOr(&W[w0 - 1], m1);
-    if (m2) atomicOr(&W[w0 - 2], m2);
+    const int w = q >> 5, sh = q & 31;
+    const unsigned long long lo = v << sh;
+    const unsigned hi = sh ? (unsigned)(v >> (64 - sh)) : 0u;
+    if ((unsigned)lo) atomicOr(&rb[w], (unsigned)lo);
+    if ((unsigned)(lo >> 32)) atomicOr(&rb[w + 1], (unsigned)(lo >> 32));
+    if (hi) atomicOr(&rb[w + 2], hi);
 }
 /* OR n (<= 32) bits into a forward little-endian bit buffer (LSB mode list) */
 __device__ __forceinline__ void or_bits_fwd(uint8_t* buf, int q, unsigned v, int n)
@@ -1922,13 +1949,13 @@ __device__ __forceinline__ void ari_chunk(AriSt& w, unsigned* big, int lane, uns
 STAGE void st_bitstream(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ C, WaveLds& L, int lane)
 {
     int* isc = L.isc;
-    uint8_t* bytes = BYTES(L);
+    unsigned* rb = (unsigned*)BYTES(L);              /* backward bit string while coding; the finished frame at the end */
     unsigned* big = BIG(L); unsigned* syml = SYML(L);
     SUB_BEGIN();
     const int nbytes = CI(nbytes);
     /* the spectrum in A is dead from here on: clear the frame (whole words up to nbytes) and the words of the code value a
      * frame of nbytes can reach */
-    for (int i = lane; i < (nbytes >> 2) + 3; i += WAVE) { ((uint32_t*)bytes)[i] = 0; big[BIGW - i] = 0; }
+    for (int i = lane; i < (nbytes >> 2) + 3; i += WAVE) { rb[i] = 0; big[BIGW - i] = 0; }
     LSYNC();
     const int nfilt = uni(isc[I_TNS_NF]);
     const int lastnz = uni(isc[I_LASTNZ]), lsbMode = uni(isc[I_LSB]), nres = uni(isc[I_NRES]);
@@ -1963,7 +1990,7 @@ STAGE void st_bitstream(const lc3d_plan* __restrict__ P, const lc3d_chan* __rest
         FIELD(15, fac_ns, 3);
 #undef FIELD
         const int incl = wave_incl_scan_i(n, lane);
-        or_bits_back(bytes, nbytes, incl - n, (unsigned long long)(unsigned)v, n);
+        or_bits_back(rb, incl - n, (unsigned long long)(unsigned)v, n);
         Q = __builtin_amdgcn_readlane(incl, 63);
     }
     if (lane == 0) { isc[I_BP_SIDE] = nbytes - 1 - (Q >> 3); isc[I_MASK_SIDE] = 1 << (Q & 7); }
@@ -1985,26 +2012,33 @@ STAGE void st_bitstream(const lc3d_plan* __restrict__ P, const lc3d_chan* __rest
     /* ---- spectrum: 64 tuples per pass ---- */
     const int ntup = (lastnz + 1) >> 1;
     int nl = 0;                                   /* LSB-mode list length */
+    /* The table reads of a pass (final symbol; escape models: context LUT, then the symbol) have long latencies and feed only the
+     * symbol list, so they are issued one pass ahead: pass p+1's reads are in flight while pass p is coded. */
+    uint32_t cdvN = 0; unsigned fsymN = 0; int x0N = 0, x1N = 0, lu0N = 0, lu1N = 0, lu2N = 0, lu3N = 0;
+#define LOAD_PASS(c0_) do { const int p_ = (c0_) + lane; const bool act_ = p_ < ntup; \
+        cdvN = act_ ? cdw[p_] : 0u; x0N = act_ ? xq[2 * p_] : 0; x1N = act_ ? xq[2 * p_ + 1] : 0; \
+        fsymN = act_ ? lc3t_ac_sym[((cdvN >> 16) & 63) * 17 + ((cdvN >> 22) & 31)] : 0u; \
+        const int ctx_ = cdvN & 1023, ne_ = act_ ? (int)((cdvN >> 10) & 63) - 1 : 0; \
+        if (__ballot(ne_ > 0)) { if (ne_ > 0) lu0N = lc3t_ac_ctx_lut[ctx_]; \
+            if (__ballot(ne_ > 1)) { if (ne_ > 1) lu1N = lc3t_ac_ctx_lut[ctx_ + 1024]; \
+                if (__ballot(ne_ > 2)) { if (ne_ > 2) lu2N = lc3t_ac_ctx_lut[ctx_ + 2048]; if (ne_ > 3) lu3N = lc3t_ac_ctx_lut[ctx_ + 3072]; } } } } while (0)
+    if (ntup > 0) LOAD_PASS(0);
     for (int c0 = 0; c0 < ntup; c0 += WAVE) {
         const int p = c0 + lane; const bool act = p < ntup;
-        const uint32_t cdv = act ? cdw[p] : 0u;
-        const unsigned fsym = act ? lc3t_ac_sym[((cdv >> 16) & 63) * 17 + ((cdv >> 22) & 31)] : 0u;
-        const int x0 = act ? xq[2 * p] : 0, x1 = act ? xq[2 * p + 1] : 0;
+        const uint32_t cdv = cdvN; const unsigned fsym = fsymN; const int x0 = x0N, x1 = x1N;
         const int a0 = x0 < 0 ? -x0 : x0, b0 = x1 < 0 ? -x1 : x1;
-        const int ctx = cdv & 1023, maxlev = act ? (int)((cdv >> 10) & 63) - 1 : -1;
+        const int maxlev = act ? (int)((cdv >> 10) & 63) - 1 : -1;
         const int nesc = maxlev > 0 ? maxlev : 0;
-        /* escape symbol (16) of the models of level classes 0..3; loads are issued only when some lane needs them */
+        /* escape symbol (16) of the models of level classes 0..3 */
         unsigned e0 = 0, e1 = 0, e2 = 0, e3 = 0;
         if (__ballot(nesc > 0)) {
-            if (nesc > 0) e0 = lc3t_ac_sym[lc3t_ac_ctx_lut[ctx] * 17 + 16];
+            if (nesc > 0) e0 = lc3t_ac_sym[lu0N * 17 + 16];
             if (__ballot(nesc > 1)) {
-                if (nesc > 1) e1 = lc3t_ac_sym[lc3t_ac_ctx_lut[ctx + 1024] * 17 + 16];
-                if (__ballot(nesc > 2)) {
-                    if (nesc > 2) e2 = lc3t_ac_sym[lc3t_ac_ctx_lut[ctx + 2048] * 17 + 16];
-                    if (nesc > 3) e3 = lc3t_ac_sym[lc3t_ac_ctx_lut[ctx + 3072] * 17 + 16];
-                }
+                if (nesc > 1) e1 = lc3t_ac_sym[lu1N * 17 + 16];
+                if (__ballot(nesc > 2)) { if (nesc > 2) e2 = lc3t_ac_sym[lu2N * 17 + 16]; if (nesc > 3) e3 = lc3t_ac_sym[lu3N * 17 + 16]; }
             }
         }
+        if (c0 + WAVE < ntup) LOAD_PASS(c0 + WAVE);
         /* backward bits of this tuple: escape LSB pairs, then signs (R/ari_codec.c:700-757) */
         unsigned long long bits = 0; int n = 0;
         for (int lev = 0; lev < maxlev; lev++) {
@@ -2023,7 +2057,7 @@ STAGE void st_bitstream(const lc3d_plan* __restrict__ P, const lc3d_chan* __rest
         if (a != 0) { bits |= (unsigned long long)(x0 < 0) << n; n++; }
         if (b != 0) { bits |= (unsigned long long)(x1 < 0) << n; n++; }
         const int incl = wave_incl_scan_i(n, lane);
-        or_bits_back(bytes, nbytes, Q + incl - n, bits, n);
+        or_bits_back(rb, Q + incl - n, bits, n);
         Q += __builtin_amdgcn_readlane(incl, 63);
         if (lsbMode == 1) {
             const int li = wave_incl_scan_i(ln, lane);
@@ -2059,6 +2093,7 @@ STAGE void st_bitstream(const lc3d_plan* __restrict__ P, const lc3d_chan* __rest
         }
         SUB(18);
     }
+#undef LOAD_PASS
     /* ---- residual / LSB bits (R/ari_codec.c:764-797); bp + pending bytes of the reference = number of shifts ---- */
     const int total = CI(total_bits);
     const int bp_side = nbytes - 1 - (Q >> 3), mask_log = Q & 7;
@@ -2070,7 +2105,7 @@ STAGE void st_bitstream(const lc3d_plan* __restrict__ P, const lc3d_chan* __rest
     LSYNC();                                        /* LSB list / residual bits and the code value are complete */
     for (int k0 = 32 * lane; k0 < nres_enc; k0 += 32 * WAVE) {
         const unsigned wv = ((const unsigned*)resb)[k0 >> 5];
-        or_bits_back(bytes, nbytes, Q + k0, wv, imin(32, nres_enc - k0));
+        or_bits_back(rb, Q + k0, wv, imin(32, nres_enc - k0));
     }
     SUB(19);
     /* ---- finalise (R/ari_codec.c:573-647) ---- */
@@ -2105,12 +2140,36 @@ STAGE void st_bitstream(const lc3d_plan* __restrict__ P, const lc3d_chan* __rest
     unsigned lastm = nb ? (0xFFu << (8 - nb)) & 0xFFu : 0u;
     if (ff_last && nb < 8) lastm = 0;
     LSYNC();
-    for (int k = lane; 4 * k < F; k += WAVE) {
-        const unsigned fw = __builtin_bswap32(big[BIGW - 1 - k]);
-        const int full = imin(4, imax(0, F - 1 - 4 * k));
-        unsigned mw = full >= 4 ? 0xFFFFFFFFu : ((1u << (8 * full)) - 1u);
-        if (full < 4 && 4 * k + full == F - 1) mw |= lastm << (8 * full);
-        ((unsigned*)bytes)[k] |= fw & mw;
+    /* assemble the frame in place: word k = frame bytes 4k..4k+3 = forward bytes (code value, byte-reversed words of big[]) OR
+     * backward bytes (rb bytes nbytes-1-4k .. nbytes-4-4k, reversed).  Every lane reads all its sources before anyone writes. */
+    {
+        const uint8_t* rbb = (const uint8_t*)rb;
+        unsigned outw[3]; const int nw = (nbytes + 3) >> 2;
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+            const int k = lane + WAVE * r;
+            unsigned o = 0;
+            if (k < nw) {
+                if (4 * k < F) {
+                    const unsigned fw = __builtin_bswap32(big[BIGW - 1 - k]);
+                    const int full = imin(4, imax(0, F - 1 - 4 * k));
+                    unsigned mw = full >= 4 ? 0xFFFFFFFFu : ((1u << (8 * full)) - 1u);
+                    if (full < 4 && 4 * k + full == F - 1) mw |= lastm << (8 * full);
+                    o = fw & mw;
+                }
+                /* rb bytes at offsets b0 .. b0+3 (b0 = nbytes-4-4k, may be -3..-1 for the last word: those frame bytes do not exist) */
+                const int b0 = nbytes - 4 - 4 * k;
+                const int wq = b0 >> 2, sh = 8 * (b0 & 3);                 /* arithmetic shift: wq = -1 for negative b0 */
+                const unsigned w0 = wq >= 0 ? rb[wq] : 0u, w1 = rb[wq + 1];
+                const unsigned v = sh ? (w0 >> sh) | (w1 << (32 - sh)) : w0;
+                o |= __builtin_bswap32(v);
+            }
+            outw[r] = o;
+        }
+        (void)rbb;
+        LSYNC();
+#pragma unroll
+        for (int r = 0; r < 3; r++) { const int k = lane + WAVE * r; if (k < nw) rb[k] = outw[r]; }
     }
     LSYNC();
     SUB(20);
