@@ -1245,9 +1245,13 @@ __device__ __forceinline__ TnsGeom tns_geom(WaveLds& L, int bw_idx, int bw_bin)
 
 /* LPC weighting (total_bits < 480 only): polynomial weighting + step-down back to reflection coefficients,
  * R/tns_coder.c:91-155,279-287.  Rare and index-heavy: lane 0 works in LDS scratch sc[]: a_in[9] at 36, rc_in[8] at 46. */
-STAGE void tns_lpc_weight(WaveLds& L, int lane, int maxOrder, float maxPG, float predGain)
+/* per-filter TNS scratch: work area sc[64] (LPC weighting 0..35, a[] 36.., rc[] 46.., predGain 63) and quantised rc[8] */
+#define TNS_SC(L, f)  (&(L).sm[(f) ? SM_PVQ : SM_MISC + 112])
+#define TNS_RCS(L, f) (&(L).sm[(f) ? SM_PVQ + 64 : SM_MISC + 104])
+
+STAGE void tns_lpc_weight(WaveLds& L, int lane, int f, int maxOrder, float maxPG, float predGain)
 {
-    float* sc = &L.sm[SM_MISC + 112];
+    float* sc = TNS_SC(L, f);
     if (lane == 0) {
         float* pa = sc + 56;                /* 9 */
         pa[0] = 1;
@@ -1279,14 +1283,16 @@ STAGE void tns_lpc_weight(WaveLds& L, int lane, int maxOrder, float maxPG, float
     LSYNC();
 }
 
-/* Levinson-Durbin (R/tns_coder.c:41-89) and prediction gain of filter f; wave-uniform, fully unrolled for register residency.
- * Returns 0: filter off, 1: on, 2: on and LPC weighting required.  Leaves a[] at sc[36..], rc[] at sc[46..], predGain at sc[63]. */
-STAGE int tns_levinson(WaveLds& L, int lane, int f, int maxOrder, float maxPG)
+/* Levinson-Durbin (R/tns_coder.c:41-89) and prediction gain; the two filters are independent up to here, so lane f runs filter f
+ * (fully unrolled for register residency).  Code 0: filter off, 1: on, 2: on and LPC weighting required; lane f leaves a[] at
+ * sc[36..], rc[] at sc[46..], predGain at sc[63] of its filter's scratch.  Returns code0 | code1 << 2. */
+STAGE int tns_levinson(WaveLds& L, int lane, int nf, int maxOrder, float maxPG)
 {
-    const float* racc = &L.sm[SM_MISC];
+    const int f = lane & 1;
+    const float* racc = &L.sm[SM_MISC + 64 + f * 9];
     float r[9], a[9], rc[8], buf[9];
 #pragma unroll
-    for (int i = 0; i < 9; i++) { r[i] = unif(racc[64 + f * 9 + i]); a[i] = 0; }
+    for (int i = 0; i < 9; i++) { r[i] = racc[i]; a[i] = 0; }
     float g = r[1] / r[0];
     a[0] = g;
     float v = (float)((1.0 - (double)(g * g)) * (double)r[0]);
@@ -1309,64 +1315,68 @@ STAGE int tns_levinson(WaveLds& L, int lane, int f, int maxOrder, float maxPG)
     }
     const float predGain = r[0] / v;
     const int tns = predGain > 1.5f;
-    if (lane == 0) {
-        float* sc = &L.sm[SM_MISC + 112];
+    if (lane < nf) {
+        float* sc = TNS_SC(L, f);
 #pragma unroll
         for (int j = 0; j < 9; j++) sc[36 + j] = a[j];
 #pragma unroll
         for (int j = 0; j < 8; j++) sc[46 + j] = rc[j];
         sc[63] = predGain;
     }
+    const int code = tns ? (predGain < maxPG ? 2 : 1) : 0;
     LSYNC();
-    return tns ? (predGain < maxPG ? 2 : 1) : 0;
+    return __builtin_amdgcn_readlane(code, 0) | (nf > 1 ? __builtin_amdgcn_readlane(code, 1) << 2 : 0);
 }
 
-/* reflection-coefficient quantisation, order and bit count of filter f (R/tns_coder.c:289-336); `code` from tns_levinson.
- * Results: quantised rc -> sm[SM_MISC+104..], order / indices -> isc.  Returns the bits this filter adds (flag included). */
-STAGE int tns_quant(WaveLds& L, int lane, int f, int maxOrder, int obits_off, int code)
+/* reflection-coefficient quantisation, order and bit count (R/tns_coder.c:289-336) of both filters: lanes 0-31 serve filter 0,
+ * lanes 32-63 filter 1; `codes` from tns_levinson.  Results: quantised rc -> TNS_RCS(f), order / indices -> isc.  Returns the
+ * bits the filters add (flags included). */
+STAGE int tns_quant(WaveLds& L, int lane, int nf, int maxOrder, int obits_off, int codes)
 {
-    float* rcs = &L.sm[SM_MISC + 104];
-    const float* sc = &L.sm[SM_MISC + 112];
+    const int f = lane >> 5, l5 = lane & 31;
+    const int code = (codes >> (2 * f)) & 3;
+    const bool live = f < nf;
+    float* rcs = TNS_RCS(L, f);
+    const float* sc = TNS_SC(L, f);
     float rc[8];
 #pragma unroll
-    for (int i = 0; i < 8; i++) rc[i] = i < maxOrder ? unif(sc[(code == 2 ? 9 : 46) + i]) : 0.0f;
-    int tns = code != 0;
-    int bits = 1, ord = 0; int idxq[8];
-    if (tns) {
-        {   /* R/tns_coder.c:157-168 findRC_idx: lane q tests its interval (thr[q], thr[q+1]] for every coefficient; the
-             * intervals are disjoint, so the ballot has at most one bit set (none -> 0, as in the reference) */
-            const float tlo = lc3t_tns_rc_thr[lane < 17 ? lane : 0], thi = lc3t_tns_rc_thr[lane < 17 ? lane + 1 : 1];
+    for (int i = 0; i < 8; i++) rc[i] = (i < maxOrder && live) ? sc[(code == 2 ? 9 : 46) + i] : 0.0f;
+    int tns = live && code != 0;
+    int bits = live ? 1 : 0, ord = 0; int idxq[8];
+    {   /* R/tns_coder.c:157-168 findRC_idx: lane q of a half tests its interval (thr[q], thr[q+1]] for every coefficient; the
+         * intervals are disjoint, so each half of the ballot has at most one bit set (none -> 0, as in the reference) */
+        const float tlo = lc3t_tns_rc_thr[l5 < 17 ? l5 : 0], thi = lc3t_tns_rc_thr[l5 < 17 ? l5 + 1 : 1];
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const unsigned long long hit = __ballot(lane < 17 && rc[i] <= thi && rc[i] > tlo);
-                idxq[i] = (i < maxOrder && hit) ? 63 - __clzll((long long)hit) : 0;
-            }
+        for (int i = 0; i < 8; i++) {
+            const unsigned long long hit = __ballot(l5 < 17 && rc[i] <= thi && rc[i] > tlo);
+            const unsigned hh = f ? (unsigned)(hit >> 32) : (unsigned)hit;
+            idxq[i] = (i < maxOrder && hh) ? 31 - __clz((int)hh) : 0;
         }
-#pragma unroll
-        for (int i = 0; i < 8; i++) { const float q = i < maxOrder ? lc3t_tns_rc_pts[idxq[i]] : 0.0f; rc[i] = q; if (i < maxOrder && q != 0) ord = i + 1; }
-        if (ord == 0) tns = 0;            /* would be undefined behaviour in the reference (R/tns_coder.c:311-321); filter off */
     }
+#pragma unroll
+    for (int i = 0; i < 8; i++) { const float q = (i < maxOrder && tns) ? lc3t_tns_rc_pts[idxq[i]] : 0.0f; rc[i] = q; if (i < maxOrder && q != 0) ord = i + 1; }
+    if (ord == 0) tns = 0;            /* would be undefined behaviour in the reference (R/tns_coder.c:311-321); filter off */
     if (tns) {
         int tmp = lc3t_tns_order_bits[obits_off + ord - 1];
 #pragma unroll
         for (int i = 0; i < 8; i++) if (i < ord) tmp += lc3t_tns_coef_bits[i * 17 + idxq[i]];
         bits += (tmp + 2047) >> 11;
     }
-    if (lane == 0) {
+    if (l5 == 0 && live) {
         L.isc[I_TNS_ORD0 + f] = tns ? ord : 0;
 #pragma unroll
         for (int i = 0; i < 8; i++) { if (tns && i < ord) L.isc[I_TNS_IDX0 + f * 8 + i] = idxq[i]; rcs[i] = rc[i]; }
     }
     LSYNC();
-    return bits;
+    return __builtin_amdgcn_readlane(bits, 0) + __builtin_amdgcn_readlane(bits, 32);
 }
 
 /* Lattice MA filter of one TNS filter (R/tns_coder.c:339-357), lane-parallel with exact replay: each lane owns a run of
  * consecutive bins and first replays the 8 preceding inputs; bins before the filter start come from the carried state. */
-STAGE void tns_lattice(WaveLds& L, int lane, int b_first, int cnt, int ord)
+STAGE void tns_lattice(WaveLds& L, int lane, int f, int b_first, int cnt, int ord)
 {
     float* stt = &L.sm[SM_MISC + 96];
-    const float* rcs = &L.sm[SM_MISC + 104];
+    const float* rcs = TNS_RCS(L, f);
     float* X = XCUR(L);
     float rc[8], st[8], carried[8];
 #pragma unroll
@@ -1466,18 +1476,18 @@ __device__ __forceinline__ void st_tns(const lc3d_plan* __restrict__ P, WaveLds&
     tns_sums(L, lane, bw_idx, bw_bin);
     SUB(21);
     const TnsGeom G = tns_geom(L, bw_idx, bw_bin);
-    int bits = 0;
+    const int codes = tns_levinson(L, lane, G.numfilters, G.maxOrder, G.maxPG);
+    for (int f = 0; f < G.numfilters; f++)
+        if (((codes >> (2 * f)) & 3) == 2) tns_lpc_weight(L, lane, f, G.maxOrder, G.maxPG, unif(TNS_SC(L, f)[63]));
+    SUB(22);
+    const int bits = tns_quant(L, lane, G.numfilters, G.maxOrder, G.obits_off, codes);
+    SUB(23);
     for (int f = 0; f < G.numfilters; f++) {
-        const int code = tns_levinson(L, lane, f, G.maxOrder, G.maxPG);
-        if (code == 2) tns_lpc_weight(L, lane, G.maxOrder, G.maxPG, unif(L.sm[SM_MISC + 112 + 63]));
-        SUB(22);
-        bits += tns_quant(L, lane, f, G.maxOrder, G.obits_off, code);
-        SUB(23);
         const int ord = uni(L.isc[I_TNS_ORD0 + f]);
         const int fstart = f ? G.start1 : G.start0, fstop = f ? G.stop1 : G.stop0;
-        if (ord > 0) tns_lattice(L, lane, fstart - 1, fstop - fstart + 1, ord);
-        SUB(24);
+        if (ord > 0) tns_lattice(L, lane, f, fstart - 1, fstop - fstart + 1, ord);
     }
+    SUB(24);
     if (lane == 0) { L.isc[I_TNS_NF] = G.numfilters; L.isc[I_TNS_BITS] = bits; }
     LSYNC();
 }
@@ -1492,6 +1502,7 @@ __device__ __forceinline__ void st_tns(const lc3d_plan* __restrict__ P, WaveLds&
  * branch (a taken branch costs ~30 cycles on this chain, a v_cndmask 8) */
 __device__ __forceinline__ float opaque(float v) { asm volatile("" : "+v"(v)); return v; }
 __device__ __forceinline__ double opaque_d(double v) { asm volatile("" : "+v"(v)); return v; }
+__device__ __forceinline__ int opaque_i(int v) { asm volatile("" : "+v"(v)); return v; }
 
 /* number of leading (low-j) energies a probe has to visit: while even the smallest candidate of the wave sees
  * en[j] - cand < thr7 and no lane has left the all-zero state, a step is a no-op, so the trailing run of such j is skipped */
@@ -1512,11 +1523,12 @@ __device__ __forceinline__ bool gain_probe(float thr7, float thr50, const float*
      * selected off the serial chain, which is then cvt - add - add - cvt; double-precision instructions cost twice a float one, so
      * as much of the selection as possible happens in float. */
     const double c_lo = (2.7) * (28.0 / 20.0), c_hi = -((50.0) * (28.0 / 20.0));
-#define GSTEP(ev) do { const float t = (ev) - fc; const bool lo = t < thr7, hi = t > thr50; \
+    /* Y in halves: lo and hi exclude each other, c_hi has a zero low word */
+    const int clo_h = __double2hiint(c_lo), clo_l = __double2loint(c_lo), chi_h = __double2hiint(c_hi);
+#define GSTEP(ev) do { const float t = (ev) - fc; const bool lo = t < thr7, hi = t > thr50, lonz = lo && !iszero; \
         const float x_hi = opaque(hi ? t + t : t), xf = opaque(lo ? 0.0f : x_hi);            /* 2t is exact in float */ \
-        const double y_lo = opaque_d(iszero ? 0.0 : c_lo), y_hi = opaque_d(hi ? c_hi : 0.0); \
-        const double Y = opaque_d(lo ? y_lo : y_hi); \
-        ener = (float)(((double)ener + (double)xf) + Y); iszero = iszero && lo; } while (0)
+        const int y_h0 = opaque_i(hi ? chi_h : 0), y_h = opaque_i(lonz ? clo_h : y_h0), y_l = opaque_i(lonz ? clo_l : 0); \
+        ener = (float)(((double)ener + (double)xf) + __hiloint2double(y_h, y_l)); iszero = iszero && lo; } while (0)
     int j = nq - 1;
     for (; j >= 3; j -= 4) { const float v0 = en[j], v1 = en[j - 1], v2 = en[j - 2], v3 = en[j - 3]; GSTEP(v0); GSTEP(v1); GSTEP(v2); GSTEP(v3); }
     for (; j >= 0; j--) GSTEP(en[j]);
@@ -1920,19 +1932,30 @@ __device__ __forceinline__ void big_add(unsigned* big, unsigned v, int s)
 
 struct AriSt { int range, s8; int pa; };         /* range, 8 * shifts so far; pa (per lane): the c_j this lane added since the last shift */
 
-/* code up to 64 symbols: lane j < cnt holds symbol j as cum | freq << 16 */
+template <int LANE> __device__ __forceinline__ int writelane_c(int vec, int val)
+{ asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(vec) : "s"(val), "n"(LANE)); return vec; }
+
+/* code up to 64 symbols: lane j < cnt holds symbol j as cum | freq << 16.
+ * Serial part, per symbol: r = range >> 10; range = r * freq, shifted left by whole bytes until >= 2^16.  `R` carries range << 8, so
+ * the renormalising shift is simply clz(r * freq) & 24 (clz 8..15 -> 8, 16..23 -> 16, 24..25 -> 24).  Groups of eight symbols run
+ * with compile-time lane numbers; the rest of a chunk takes the generic loop. */
 __device__ __forceinline__ void ari_chunk(AriSt& w, unsigned* big, int lane, unsigned vsym, int cnt)
 {
     const int vfreq = (int)(vsym >> 16), vcum = (int)(vsym & 0xffffu);
-    int vr = 0, rg = w.range, k = 0;
-#define ARI_STEP(kk) do { const int f_ = __builtin_amdgcn_readlane(vfreq, (kk)); const int r_ = (int)((unsigned)rg >> 10); \
-        vr = writelane(vr, r_, (kk)); rg = r_ * f_; rg <<= ((__builtin_clz(rg) - 8) & 24); } while (0)
-    for (; k + 8 <= cnt; k += 8) {
-#pragma unroll
-        for (int u = 0; u < 8; u++) ARI_STEP(k + u);
+    int vr = 0, k = 0;
+    unsigned R = (unsigned)w.range << 8;
+#define ARI_STEP_C(LN) do { const int f_ = __builtin_amdgcn_readlane(vfreq, (LN)); const int r_ = (int)(R >> 18); \
+        vr = writelane_c<(LN)>(vr, r_); const unsigned rp_ = (unsigned)(r_ * f_); R = rp_ << (__builtin_clz(rp_) & 24); } while (0)
+#define ARI_GROUP(G) if (cnt >= 8 * (G) + 8) { ARI_STEP_C(8 * (G)); ARI_STEP_C(8 * (G) + 1); ARI_STEP_C(8 * (G) + 2); ARI_STEP_C(8 * (G) + 3); \
+        ARI_STEP_C(8 * (G) + 4); ARI_STEP_C(8 * (G) + 5); ARI_STEP_C(8 * (G) + 6); ARI_STEP_C(8 * (G) + 7); k = 8 * (G) + 8;
+    ARI_GROUP(0) ARI_GROUP(1) ARI_GROUP(2) ARI_GROUP(3) ARI_GROUP(4) ARI_GROUP(5) ARI_GROUP(6) ARI_GROUP(7) }}}}}}}}
+#undef ARI_GROUP
+#undef ARI_STEP_C
+    for (; k < cnt; k++) {
+        const int f_ = __builtin_amdgcn_readlane(vfreq, k); const int r_ = (int)(R >> 18);
+        vr = writelane(vr, r_, k); const unsigned rp_ = (unsigned)(r_ * f_); R = rp_ << (__builtin_clz(rp_) & 24);
     }
-    for (; k < cnt; k++) ARI_STEP(k);
-#undef ARI_STEP
+    const int rg = (int)(R >> 8);
     w.range = rg;
     const bool on = lane < cnt;
     const int rng2 = on ? vr * vfreq : 0x10000;                         /* this symbol's range before renormalisation */
