@@ -342,7 +342,7 @@ STAGE void st_resample(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
     SUB_BEGIN();
     /* polyphase FIR, R/resamp12k8.c:48-57: out[n] = sum_m (buf[.]*sf) * lp[.] in the reference's tap order.  The scaled samples
      * are formed once (sm is idle here); a lane's two outputs (n = lane, lane + 64) share one phase, whose taps are held in
-     * registers 30 at a time. */
+     * registers 15 at a time. */
     float* xs = L.sm;
     for (int j = lane; j < mlen + N; j += WAVE) xs[j] = buf[j] * sf;
     LSYNC();
@@ -356,12 +356,12 @@ STAGE void st_resample(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
         if (!on0) b0 = xs;                            /* idle lanes read in bounds */
         if (!on1) b1 = xs;
         float m0 = 0, m1 = 0;
-        for (int tb = 0; tb < T; tb += 30) {
-            float tap[30];
+        for (int tb = 0; tb < T; tb += 15) {          /* T = 30, 60 or 120; 15 taps at a time keeps the stage inside its register budget */
+            float tap[15];
 #pragma unroll
-            for (int m = 0; m < 30; m++) tap[m] = tp[tb + m];
+            for (int m = 0; m < 15; m++) tap[m] = tp[tb + m];
 #pragma unroll
-            for (int m = 0; m < 30; m++) { m0 += b0[tb + m] * tap[m]; m1 += b1[tb + m] * tap[m]; }
+            for (int m = 0; m < 15; m++) { m0 += b0[tb + m] * tap[m]; m1 += b1[tb + m] * tap[m]; }
         }
         d[0] = on0 ? m0 : 0.0f; d[1] = on1 ? m1 : 0.0f;
     }
