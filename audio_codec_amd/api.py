@@ -31,7 +31,8 @@ class LC3Error(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(HERE, "liblc3plus_hip.so")
+    # LC3PLUS_HIP_LIB selects another build of the same library (diagnostic builds: stage timing / stage counts)
+    return os.environ.get("LC3PLUS_HIP_LIB") or os.path.join(HERE, "liblc3plus_hip.so")
 
 
 def load_library():

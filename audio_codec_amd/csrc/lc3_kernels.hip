@@ -42,6 +42,12 @@
 #define TICK(id) do { long long now_ = clock64(); if (lane == 0) L.tacc[id] += now_ - tlast; tlast = now_; } while (0)
 #define SUB_BEGIN() long long ts_ = clock64()
 #define SUB(id) do { long long n_ = clock64(); if (lane == 0) L.tacc[24 + (id)] += n_ - ts_; ts_ = n_; } while (0)
+#elif defined(LC3_STOP_AFTER)
+/* Diagnostic build only (tools/stage_counts.sh): every frame ends after stage LC3_STOP_AFTER, so that instruction counters of
+ * consecutive variants differ by exactly one stage.  Output bytes are meaningless in such a build. */
+#define TICK(id) if ((id) == LC3_STOP_AFTER) continue
+#define SUB_BEGIN() do { } while (0)
+#define SUB(id) do { } while (0)
 #else
 #define TICK(id) do { } while (0)
 #define SUB_BEGIN() do { } while (0)
