@@ -963,58 +963,79 @@ STAGE void st_sns_scf(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
 }
 
 /* ---- PVQ pulse search R/sns_quantize_scf.c:43-136: one search per lane, everything in registers ---- */
-/* PVQ pulse search R/sns_quantize_scf.c:43-136, one lane per search, state in registers.  Written branch-free: dimensions beyond
- * `dim` carry |x| = 0 (adding +0 is exact, so the serial sums need no guard) and are masked out of the candidate scan; every
- * decision is a select, because a divergent branch costs more than the whole 16-candidate chain step it would skip. */
-__device__ __forceinline__ void pvq_search_reg(WaveLds& L, const float* x_in, int dim, int pulses, int* y_out, float* yn_out)
+/* PVQ pulse searches R/sns_quantize_scf.c:43-136: the four searches (N=10,K=10 | N=6,K=1 on tgt+10 | N=16,K=8 | N=16,K=6) run side
+ * by side, one per 16-lane row, lane i of a row owning dimension i.  What the reference does serially over the dimensions is
+ * kept in its order: the sums xsum and xy are re-added by every lane from row-wide LDS arrays, and the candidate scan
+ *     for i: if (a_i * cden > b_i * cnum) take i
+ * (a float cross-multiplication, not a total order, so it cannot become a tree reduction) is replayed by every lane over the
+ * row's (a, b) pairs read back from LDS - 6 VALU per candidate instead of 10, for four searches at once.  Dimensions beyond a
+ * search's N carry |x| = 0 and b = +INF: a*cden > INF*cnum is false for every cnum >= 0, and cnum >= 0 from candidate 0 on. */
+__device__ __forceinline__ void pvq_search_rows(WaveLds& L, int lane, const float* tgt, float* pv)
 {
-    float xabs[16], yf[16];                          /* yf: pulse counts as floats (small integers, exact) */
-    float xsum = 0, yy = 0, xy = 0, totf = 0; unsigned negm = 0;
+    const int s = lane >> 4, i = lane & 15;
+    const int dim = s == 0 ? 10 : s == 1 ? 6 : 16, K = s == 0 ? 10 : s == 1 ? 1 : s == 2 ? 8 : 6;
+    float* scr = XCUR(L);                            /* X is scratch between the MDCT and TNS: 4 arrays of 4 rows x 16 */
+    float* xs = scr + 16 * s; float* ys = scr + 64 + 16 * s; float* as = scr + 128 + 16 * s; float* bs = scr + 192 + 16 * s;
+    const float xv = tgt[(s == 1 ? 10 : 0) + i];
+    const bool valid = i < dim, neg = !(xv >= 0);
+    const float xa = valid ? fabsf(xv) : 0.0f;
+    xs[i] = xa;
+    LSYNC();
+    float xsum = 0;
 #pragma unroll
-    for (int i = 0; i < 16; i++) { const float xv = x_in[i]; xabs[i] = i < dim ? fabsf(xv) : 0.0f; negm |= (xv >= 0 ? 0u : 1u) << i; }
-#pragma unroll
-    for (int i = 0; i < 16; i++) xsum += xabs[i];
+    for (int j = 0; j < 16; j += 4) { const float4 u = *(const float4*)&xs[j]; xsum += u.x; xsum += u.y; xsum += u.z; xsum += u.w; }
     const bool live = xsum > PF(c_2m24);
-    const float proj = live ? (float)(pulses - 1) / xsum : 0.0f;
+    const float proj = live ? (float)(K - 1) / xsum : 0.0f;
+    float y = floorf(xa * proj);                     /* this dimension's pulse count: a small integer, exact in float */
+    ys[i] = y; as[i] = xa * y;
+    LSYNC();
+    float totf = 0, yy = 0, xy = 0;
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-        const float yi = floorf(xabs[i] * proj);
-        yf[i] = yi; totf += yi;
-        yy = yy + yi * yi;
-        xy = xy + xabs[i] * yi;
+    for (int j = 0; j < 16; j += 4) {
+        const float4 u = *(const float4*)&ys[j], v = *(const float4*)&as[j];
+        totf += u.x; totf += u.y; totf += u.z; totf += u.w;
+        yy = yy + u.x * u.x; yy = yy + u.y * u.y; yy = yy + u.z * u.z; yy = yy + u.w * u.w;
+        xy = xy + v.x; xy = xy + v.y; xy = xy + v.z; xy = xy + v.w;
     }
-    int tot = live ? (int)totf : pulses;
-    /* dimensions beyond dim must never win the scan: +INF as their pulse count makes b = INF, and a*cden > INF*cnum is false for
-     * every cnum >= 0 (INF*0 = NaN compares false); cnum is >= 0 from candidate 0 on, which always exists */
-#pragma unroll
-    for (int i = 0; i < 16; i++) yf[i] = i < dim ? yf[i] : INFINITY;
+    int tot = live ? (int)totf : K;
     yy = yy * 0.5f;
-    while (tot < pulses) {
-        int imx = 0; float cnum = -PF(c_2p15), cden = 0, xs = 0, ys = 0;
-        yy = yy + 0.5f;
+    LSYNC();
+    while (__ballot(tot < K)) {
+        const bool act = tot < K;
+        const float yyt = yy + 0.5f;
+        float a = xy + xa; a = a * a;
+        as[i] = a; bs[i] = valid ? yyt + y : INFINITY;
+        LSYNC();
+        float cnum, cden; int best = 0;
+        {
+            const float4 ua = *(const float4*)&as[0], ub = *(const float4*)&bs[0];
+            cnum = ua.x; cden = ub.x;                /* candidate 0 always beats the initial (-2^15, 0) */
+#define PVQ_CAND(aj, bj, j) do { const bool t = (aj) * cden > (bj) * cnum; cnum = t ? (aj) : cnum; cden = t ? (bj) : cden; best = t ? (j) : best; } while (0)
+            PVQ_CAND(ua.y, ub.y, 1); PVQ_CAND(ua.z, ub.z, 2); PVQ_CAND(ua.w, ub.w, 3);
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-            float a = xy + xabs[i]; a = a * a;
-            const float b = yy + yf[i];
-            const bool t = a * cden > b * cnum;
-            cnum = t ? a : cnum; cden = t ? b : cden; imx = t ? i : imx; xs = t ? xabs[i] : xs; ys = t ? yf[i] : ys;
+            for (int j = 4; j < 16; j += 4) {
+                const float4 va = *(const float4*)&as[j], vb = *(const float4*)&bs[j];
+                PVQ_CAND(va.x, vb.x, j); PVQ_CAND(va.y, vb.y, j + 1); PVQ_CAND(va.z, vb.z, j + 2); PVQ_CAND(va.w, vb.w, j + 3);
+            }
+#undef PVQ_CAND
         }
-#pragma unroll
-        for (int i = 0; i < 16; i++) yf[i] += (i == imx) ? 1.0f : 0.0f;
-        xy = xy + xs; yy = yy + ys; tot++;
+        const float xb = xs[best], yb = ys[best];
+        LSYNC();
+        if (act) {
+            if (i == best) { y = y + 1.0f; ys[i] = y; }
+            xy = xy + xb; yy = yyt + yb; tot++;
+        }
+        LSYNC();
     }
     yy = yy * 2.0f;
     /* all-zero target: the reference puts the pulses at y[0] and (out of range) y[dim]; only y[0] is ever read back */
-    const int y0z = pulses / 2, ydz = -(pulses - pulses / 2);
+    const int y0z = K / 2, ydz = -(K - K / 2);
     if (!live) yy = (float)(y0z * y0z + ydz * ydz);
     const float g = (float)(1.0 / (double)sqrtf(yy));
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-        int ya = i < dim ? (int)yf[i] : 0;
-        if (i == 0) ya = live ? ya : y0z;
-        const int yi = ((negm >> i) & 1u) ? -ya : ya;
-        y_out[i] = yi; yn_out[i] = (float)yi * g;
-    }
+    int ya = valid ? (int)y : 0;
+    if (!live) ya = i == 0 ? y0z : 0;
+    const int yi = neg ? -ya : ya;
+    ((int*)(pv + s * 32))[i] = yi; pv[s * 32 + 16 + i] = (float)yi * g;
 }
 
 /* MPVQ enumeration R/sns_quantize_scf.c:138-163 (integer), lane-parallel.  The reference walks pos = len-1 .. 0 with
@@ -1084,12 +1105,9 @@ STAGE void st_sns_vq(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
     }
     LSYNC();
     SUB(5);
-    /* four pulse searches, one lane each: 0:(N=10,K=10) 1:(N=6,K=1 on tgt+10) 2:(N=16,K=8) 3:(N=16,K=6) */
+    /* four pulse searches, one 16-lane row each: 0:(N=10,K=10) 1:(N=6,K=1 on tgt+10) 2:(N=16,K=8) 3:(N=16,K=6) */
     float* pv = &L.sm[SM_PVQ];
-    if (lane < 4) {
-        const int dim = lane == 0 ? 10 : lane == 1 ? 6 : 16, K = lane == 0 ? 10 : lane == 1 ? 1 : lane == 2 ? 8 : 6;
-        pvq_search_reg(L, lane == 1 ? tgt + 10 : tgt, dim, K, (int*)(pv + lane * 32), pv + lane * 32 + 16);
-    }
+    pvq_search_rows(L, lane, tgt, pv);
     LSYNC();
     SUB(6);
     const int* pA = (const int*)(pv); const int* pB = (const int*)(pv + 32);
