@@ -147,6 +147,7 @@ def main():
     ap.add_argument("--streams", type=int, default=4096, help="independent mono streams per GPU (BASELINE configs[1])")
     ap.add_argument("--frames", type=int, default=64, help="frames per stream per step (SURVEY 8(d): T = 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-io", action="store_true", help="also time encode() on pageable host buffers (PCIe-inclusive; reported as host_io, never as value)")
     ap.add_argument("--workload", default="c1", choices=sorted(WORKLOADS), help="c1 = BASELINE configs[1] (the metric's configuration)")
     a = ap.parse_args()
     if a.workload != "c1":
@@ -218,6 +219,15 @@ def main():
                          "algorithmic_bytes_per_launch": B * T * ALGO_BYTES_PER_FRAME,
                          "note": "serial-chain (instruction-issue) bound, not HBM bound: see DESIGN.md"},
         }
+        if a.host_io:
+            import numpy as np
+            h_pcm = pcm.cpu().numpy()
+            batch.encode(h_pcm[:, :T])                         # warm-up (first-touch of the staging buffers)
+            th = time.perf_counter()
+            for _ in range(3): batch.encode(h_pcm[:, :T])
+            th = (time.perf_counter() - th) / 3
+            res["host_io"] = {"value": round(B * T / th / 1e6, 4), "unit": "Mframes/s", "ms_per_step": round(th * 1e3, 3),
+                              "note": "rank 0, same workload through lc3plus_enc_batch_encode with pageable host pointers (H2D + kernel + D2H, synchronous)"}
         if not a.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline()

@@ -111,7 +111,12 @@ class Oracle:
         return self.trace
 
     def set_bitrate(self, br):
-        return self.lib.lc3o_enc_set_bitrate(self.p, br)
+        rc = self.lib.lc3o_enc_set_bitrate(self.p, br)
+        self.nbytes = self.lib.lc3o_enc_get_num_bytes(self.p)
+        return rc
+
+    def set_bandwidth(self, bw):
+        return self.lib.lc3o_enc_set_bandwidth(self.p, bw)
 
     def encode(self, planar, bitdepth=16):
         """planar: [channels, N] int16 (bitdepth 16) or int32."""

@@ -180,3 +180,38 @@ def test_cli_front_end_writes_the_reference_container(tmp_path, channels, bits, 
         fr = 2 + o.nbytes
         same = sum(ref[20 + i * fr:20 + (i + 1) * fr] == got[20 + i * fr:20 + (i + 1) * fr] for i in range(38))
         assert same >= 37, same
+
+
+def test_cli_switching_files(tmp_path):
+    """-swf / -bandwidth FILE (one int64 per frame, wrapping: R/codec_exe.c:296-326,858-866) against the oracle, and against the
+    ETSI CLI when it travelled with the snapshot."""
+    import subprocess
+    from lc3_harness import ORACLE_DIR
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cli = os.path.join(root, "tools", "lc3plus_enc_cli")
+    subprocess.check_call(["make", "-s", "-C", root, "cli"])
+    nfr = 40
+    pcm = synth_pcm(1, nfr, 480, 48000, seed=77).reshape(1, -1)
+    wav = tmp_path / "in.wav"
+    _write_wav(wav, pcm.T.reshape(-1), 48000, 1, 16)
+    rates = [64000] * 7 + [32000] * 5 + [128000] * 3 + [96000] * 4         # 19 entries: wraps twice over 40 frames
+    bws = [20000] * 6 + [8000] * 9 + [16000] * 2                            # 17 entries
+    swf = tmp_path / "rates.bin"; np.array(rates, np.int64).tofile(swf)
+    bwf = tmp_path / "bw.bin"; np.array(bws, np.int64).tofile(bwf)
+    ours = tmp_path / "ours.lc3plus"
+    subprocess.check_call([cli, "-E", "-q", "-swf", str(swf), "-bandwidth", str(bwf), str(wav), str(ours), "64000"])
+    got = open(ours, "rb").read()
+    o = Oracle(48000, 1, 10.0, 0, 64000, portable_math=True)
+    frames = []
+    for t in range(nfr):
+        assert o.set_bitrate(rates[t % len(rates)]) == 0
+        o.set_bandwidth(bws[t % len(bws)])
+        frames.append(o.encode(pcm[:, t * 480:(t + 1) * 480], 16))
+    assert got == _container(frames, 48000, 64000, 1, 10.0, nfr * 480, 0)
+    ref_cli = os.path.join(ORACLE_DIR, "_ref", "LC3plus")
+    if os.path.exists(ref_cli):
+        theirs = tmp_path / "ref.lc3plus"
+        subprocess.check_call([ref_cli, "-E", "-q", "-swf", str(swf), "-bandwidth", str(bwf), str(wav), str(theirs), "64000"], stdout=subprocess.DEVNULL)
+        ref = open(theirs, "rb").read()
+        assert len(ref) == len(got) and ref[:20] == got[:20]
+        assert sum(a != b for a, b in zip(ref, got)) <= 2 * 80      # at most a couple of frames may differ at the libm boundary

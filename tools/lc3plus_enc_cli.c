@@ -7,7 +7,12 @@
  * in time: the whole file is pushed through lc3plus_enc_batch_encode() in chunks of frames so that the encoder state stays
  * on the GPU between frames of a chunk.
  *
- *   lc3plus_enc_cli [-E] [-q] [-frame_ms 2.5|5|10] [-hrmode] [-bandwidth HZ] [-formatG192] [-cfgG192 FILE] in.wav out.lc3plus BITRATE
+ *   lc3plus_enc_cli [-E] [-q] [-frame_ms 2.5|5|10] [-hrmode] [-bandwidth HZ|FILE] [-swf FILE] [-formatG192] [-cfgG192 FILE]
+ *                   in.wav out.lc3plus BITRATE|FILE
+ *
+ * Switching files (R/codec_exe.c:296-326, loopy_read64 :858-866) hold one int64 per frame and wrap around: the bitrate per channel
+ * (-swf FILE, or a file name in place of BITRATE) and the audio bandwidth in Hz (-bandwidth FILE).  Frames with equal settings are
+ * still pushed through the GPU in runs; a change of setting ends the run.
  */
 #include <stdint.h>
 #include <stdio.h>
@@ -17,6 +22,13 @@
 #include "lc3plus_batch.h"
 
 static void die(const char* msg) { fprintf(stderr, "lc3plus_enc_cli: %s\n", msg); exit(1); }
+
+static int64_t loopy_read64(FILE* f)               /* R/codec_exe.c:858-866 */
+{
+    int64_t tmp = 0;
+    if (fread(&tmp, sizeof tmp, 1, f) != 1) { fseek(f, 0, SEEK_SET); if (fread(&tmp, sizeof tmp, 1, f) != 1) die("empty switching file"); }
+    return tmp;
+}
 
 typedef struct { int rate, channels, bits; uint32_t frames; uint8_t* data; } wav_t;
 
@@ -54,19 +66,25 @@ static void read_wav(const char* path, wav_t* w)
 int main(int ac, char** av)
 {
     float frame_ms = 10; int hrmode = 0, g192 = 0, bandwidth = 0, quiet = 0; const char* cfg = NULL;
+    const char* swf = NULL; const char* bwf = NULL;
     int i = 1;
     for (; i < ac && av[i][0] == '-'; i++) {
         if (!strcmp(av[i], "-E")) continue;
         else if (!strcmp(av[i], "-q")) quiet = 1;
         else if (!strcmp(av[i], "-frame_ms") && i + 1 < ac) frame_ms = (float)atof(av[++i]);
         else if (!strcmp(av[i], "-hrmode")) hrmode = 1;
-        else if (!strcmp(av[i], "-bandwidth") && i + 1 < ac) bandwidth = atoi(av[++i]);
+        else if (!strcmp(av[i], "-bandwidth") && i + 1 < ac) { bandwidth = atoi(av[++i]); if (bandwidth == 0) bwf = av[i]; }
+        else if (!strcmp(av[i], "-swf") && i + 1 < ac) swf = av[++i];
         else if (!strcmp(av[i], "-formatG192")) g192 = 1;
         else if (!strcmp(av[i], "-cfgG192") && i + 1 < ac) cfg = av[++i];
         else die("unknown option (encode-only front end)");
     }
     if (ac - i != 3) die("usage: lc3plus_enc_cli [options] in.wav out.lc3plus bitrate");
-    const char* in = av[i]; const char* outp = av[i + 1]; const int bitrate = atoi(av[i + 2]);
+    const char* in = av[i]; const char* outp = av[i + 1]; int bitrate = atoi(av[i + 2]);
+    if (bitrate == 0) { bitrate = 64000; swf = av[i + 2]; }          /* a file name in place of the bitrate (R/codec_exe.c:598-604) */
+    FILE* fswf = swf ? fopen(swf, "rb") : NULL; FILE* fbwf = bwf ? fopen(bwf, "rb") : NULL;
+    if (swf && !fswf) die("Error opening bitrate switching file!");
+    if (bwf && !fbwf) die("Error opening bandwidth switching file!");
 
     wav_t w; read_wav(in, &w);
     if (w.bits != 16 && w.bits != 24 && w.bits != 32) die("unsupported sample width");
@@ -88,6 +106,7 @@ int main(int ac, char** av)
     if (err) { fprintf(stderr, "lc3plus_enc_cli: cannot create the GPU encoder (LC3_Error %d)\n", (int)err); return 1; }
     nbytes = lc3plus_enc_batch_num_bytes(b, 0);
     if (bandwidth) { err = lc3plus_enc_batch_set_bandwidth(b, 0, bandwidth); if (err && err < LC3_WARNING) die("bandwidth error"); }
+    if (fbwf) bandwidth = 0;
 
     FILE* fo = fopen(outp, "wb");
     if (!fo) die("Error creating bitstream file!");
@@ -110,10 +129,31 @@ int main(int ac, char** av)
     const int CH = 256;                                   /* frames per launch */
     const int wide = w.bits != 16;
     void* pcm = calloc((size_t)CH * C * N, wide ? 4 : 2);
-    uint8_t* out = (uint8_t*)malloc((size_t)CH * nbytes);
+    uint8_t* out = (uint8_t*)malloc((size_t)CH * LC3_MAX_BYTES * 2);
     const int bps = w.bits / 8;
-    for (uint32_t f0 = 0; f0 < total_frames; f0 += CH) {
-        const int T = (int)((total_frames - f0) < (uint32_t)CH ? (total_frames - f0) : (uint32_t)CH);
+    int cur_bitrate = bitrate, cur_bw = bandwidth;
+    uint32_t f0 = 0;
+    while (f0 < total_frames) {
+        /* settings of frame f0 (the reference applies them before reading the frame, R/codec_exe.c:296-326) */
+        int64_t nbr = fswf ? loopy_read64(fswf) * C : cur_bitrate, nbw = fbwf ? loopy_read64(fbwf) : cur_bw;
+        if ((int)nbr != cur_bitrate) {
+            err = lc3plus_enc_batch_set_bitrate(b, 0, (int)nbr); if (err) { fprintf(stderr, "lc3plus_enc_cli: bitrate switch failed (LC3_Error %d)\n", (int)err); return 1; }
+            cur_bitrate = (int)nbr; nbytes = lc3plus_enc_batch_num_bytes(b, 0);
+        }
+        if ((int)nbw != cur_bw) {
+            err = lc3plus_enc_batch_set_bandwidth(b, 0, (int)nbw); if (err && err < LC3_WARNING) die("bandwidth error");
+            cur_bw = (int)nbw;
+        }
+        /* extend the run while the switching files keep the settings */
+        int T = 1;
+        while (T < CH && f0 + T < total_frames) {
+            if (fswf || fbwf) {
+                const long ps = fswf ? ftell(fswf) : 0, pb = fbwf ? ftell(fbwf) : 0;
+                const int64_t br2 = fswf ? loopy_read64(fswf) * C : cur_bitrate, bw2 = fbwf ? loopy_read64(fbwf) : cur_bw;
+                if ((int)br2 != cur_bitrate || (int)bw2 != cur_bw) { if (fswf) fseek(fswf, ps, SEEK_SET); if (fbwf) fseek(fbwf, pb, SEEK_SET); break; }
+            }
+            T++;
+        }
         memset(pcm, 0, (size_t)T * C * N * (wide ? 4 : 2));
         for (int t = 0; t < T; t++) for (int n = 0; n < N; n++) {                 /* de-interleave into [frame][channel][N] */
             const uint64_t s = (uint64_t)(f0 + t) * N + n;
@@ -143,7 +183,8 @@ int main(int ac, char** av)
                 fwrite(fr, 1, nbytes, fo);
             }
         }
-        if (!quiet) { printf("\rProcessing frame %u", f0 + T); fflush(stdout); }
+        f0 += (uint32_t)T;
+        if (!quiet) { printf("\rProcessing frame %u", f0); fflush(stdout); }
     }
     if (!quiet) puts("\nProcessing done!");
     fclose(fo);
