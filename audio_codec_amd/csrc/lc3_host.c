@@ -65,9 +65,11 @@ static void geom_update(geom_t* g)                                        /* R/s
     if (g->tab) { g->nbands = g->tab->nbands; g->la = g->tab->la_zeros; }
 }
 
-/* the kernels are built for frame lengths up to LC3D_MAX_N whose N/2-point DFT is 240 (15x16) or 120 (8x3x5) and an MDCT
- * overlap memory of at most 300 samples (excludes 96 kHz / 5 ms: N = 480 with 120 leading zeros) */
-static int geom_supported(const geom_t* g) { return g->tab && g->N <= LC3D_MAX_N && (g->N == 480 || g->N == 240) && g->N - g->la <= 300; }
+/* the kernels are built for frame lengths up to LC3D_MAX_N whose N/2-point DFT has a restated kernel (240 = 15x16, 60 = 4x15, and
+ * the prime-factor lengths 10, 20, 30, 40, 80, 120; not 160 = 32x5 of 32 kHz / 10 ms, not 480) and an MDCT overlap memory of at
+ * most 300 samples (excludes 96 kHz / 5 ms: N = 480 with 120 leading zeros) */
+static int fft_supported(int len);
+static int geom_supported(const geom_t* g) { return g->tab && g->N <= LC3D_MAX_N && fft_supported(g->N / 2) && g->N - g->la <= 300; }
 
 /* R/setup_enc_lc3.c:196-375: bitrate -> per-channel budgets.  Returns an LC3_Error. */
 static LC3_Error derive_bitrate(const geom_t* g, int bitrate, lc3d_chan* ch /* [channels] */)
@@ -159,18 +161,30 @@ static void pfa_label(int* x, int length, int* scratch, int nfac, const int* fac
     }
     memcpy(x, tmp, sizeof(int) * length);
 }
-static void pfa_plan_120(lc3d_plan* p)
+/* factors: the prime powers of the length in increasing prime order (R/fft/fft_generic.h:89-145 factorize) */
+static int pfa_plan(lc3d_plan* p, int len)
 {
-    static const int fac[3] = {8, 3, 5};
-    int x[120], scratch[240];
-    pfa_rec r; memset(&r, 0, sizeof r);
-    r.src[0] = p->pfa_src; r.src[1] = p->pfa_src + 120; r.src[2] = p->pfa_src + 240;
-    r.leaf[0] = 8; r.leaf[1] = 3; r.leaf[2] = 5;
-    for (int i = 0; i < 120; i++) x[i] = i;
-    pfa_label(x, 120, scratch, 3, fac, &r);
-    /* x[i] = slot of the last stage holding output bin i  ->  pfa_dst[slot] = i */
-    for (int i = 0; i < 120; i++) p->pfa_dst[x[i]] = (uint8_t)i;
+    static const struct { int len, n, f[3]; } tab[] = {{10, 2, {2, 5, 0}}, {20, 2, {4, 5, 0}}, {30, 3, {2, 3, 5}}, {40, 2, {8, 5, 0}},
+                                                        {80, 2, {16, 5, 0}}, {120, 3, {8, 3, 5}}};
+    if (len == 60) {                                /* 4 x 15 Good-Thomas with the reference's index tables (R/fft/fft_60_128.h:18-23) */
+        for (int k = 0; k < 4; k++) for (int l = 0; l < 15; l++) { p->pfa_src[k + 4 * l] = (uint8_t)((45 * k + 16 * l) % 60); p->pfa_dst[k + 4 * l] = (uint8_t)((15 * k + 4 * l) % 60); }
+        p->pfa_nst = 0;
+        return 1;
+    }
+    for (unsigned t = 0; t < sizeof tab / sizeof tab[0]; t++) if (tab[t].len == len) {
+        int x[120], scratch[240];
+        pfa_rec r; memset(&r, 0, sizeof r);
+        for (int k = 0; k < 3; k++) { r.src[k] = p->pfa_src + 120 * k; r.leaf[k] = tab[t].f[k]; p->pfa_rad[k] = tab[t].f[k]; }
+        p->pfa_nst = tab[t].n;
+        for (int i = 0; i < len; i++) x[i] = i;
+        pfa_label(x, len, scratch, tab[t].n, tab[t].f, &r);
+        /* x[i] = slot of the last stage holding output bin i  ->  pfa_dst[slot] = i */
+        for (int i = 0; i < len; i++) p->pfa_dst[x[i]] = (uint8_t)i;
+        return 1;
+    }
+    return 0;
 }
+static int fft_supported(int len) { return len == 240 || len == 60 || len == 10 || len == 20 || len == 30 || len == 40 || len == 80 || len == 120; }
 
 /* R/util.h:109 cexpi with the reference's float argument conversion */
 static void cexpi_f(float x, float* re, float* im) { *re = cosf(x); *im = sinf(x); }
@@ -224,7 +238,7 @@ static void build_plan(const geom_t* g, lc3d_plan* p)
     memset(p->band_of_bin, 255, sizeof p->band_of_bin);
     const uint16_t* be = &lc3t_band_pool[g->tab->band_off];
     for (int b = 0; b < g->nbands; b++) for (int j = be[b]; j < be[b + 1] && j < LC3D_MAX_N; j++) p->band_of_bin[j] = (uint8_t)b;
-    if (g->N / 2 == 120) pfa_plan_120(p);
+    if (g->N / 2 != 240) pfa_plan(p, g->N / 2);
 }
 
 static void init_state(float* st)                                         /* zeroed EncSetup + olpa_mem_pitch = 17 (R/setup_enc_lc3.c:178) */

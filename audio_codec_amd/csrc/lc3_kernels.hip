@@ -64,7 +64,7 @@ struct __attribute__((aligned(16))) WaveLds {
     float h12[384];             /* HP-filtered 12.8 kHz stream, newest sample at [383] */
     float h6[194];              /* 6.4 kHz stream, newest at [193] */
     float sm[548];              /* small vectors (SM_*); from quantisation on: cdw[240] | residual / LSB bits (160 words) */
-    int   pc[42];               /* the scalar head of the plan (lc3d_plan up to pad0), copied once: stage code reads it from LDS
+    int   pc[LC3D_PLAN_HEAD_WORDS];  /* the scalar head of the plan (lc3d_plan up to pad0), copied once: stage code reads it from LDS
                                    instead of through a flat pointer, and readfirstlane makes the values scalar */
     int   cc[14];               /* this channel-stream's lc3d_chan */
     float fsc[12];              /* float scalars: cross-frame state + values passed between stages */
@@ -73,6 +73,7 @@ struct __attribute__((aligned(16))) WaveLds {
     long long tacc[NSTAGE];
 #endif
 };
+static_assert(offsetof(lc3d_plan, tw1) == 4 * LC3D_PLAN_HEAD_WORDS, "plan head size");
 static_assert(offsetof(WaveLds, A) % 16 == 0 && (offsetof(WaveLds, sm) + 242 * 4) % 16 == 0 && offsetof(WaveLds, xbuf) == 0, "16-byte aligned LDS rows");
 #define PI(f) uni(L.pc[offsetof(lc3d_plan, f) / 4])
 #define PF(f) __int_as_float(uni(L.pc[offsetof(lc3d_plan, f) / 4]))
@@ -314,6 +315,13 @@ __device__ __forceinline__ void dft3(float* v)
     v[2] = r1 - C1 * sr + C2 * di;    v[4] = r1 - C1 * sr - C2 * di;
     v[3] = i1 - C2 * dr - C1 * si;    v[5] = i1 + C2 * dr - C1 * si;
 }
+__device__ __forceinline__ void dft4(float* v)      /* R/fft/fft_2_9.h:69-92 (forms im(x3) - im(x1), not its negative) */
+{
+    const float sr = v[0] + v[4], dr = v[0] - v[4], si = v[1] + v[5], di = v[1] - v[5];
+    const float tr = v[2] + v[6], ur = v[2] - v[6], ti = v[7] + v[3], ui = v[7] - v[3];
+    v[0] = sr + tr; v[1] = si + ti; v[2] = dr - ui; v[3] = di - ur;
+    v[4] = sr - tr; v[5] = si - ti; v[6] = dr + ui; v[7] = di + ur;
+}
 __device__ __forceinline__ void dft5(float* v)
 {
     const float C1 = 0.309016994374947f, C2 = 0.951056516295154f, C3 = 0.809016994374947f, C4 = 0.587785252292473f;
@@ -348,7 +356,7 @@ STAGE void st_resample(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
     SUB_BEGIN();
     /* polyphase FIR, R/resamp12k8.c:48-57: out[n] = sum_m (buf[.]*sf) * lp[.] in the reference's tap order.  The scaled samples
      * are formed once (sm is idle here); a lane's two outputs (n = lane, lane + 64) share one phase, whose taps are held in
-     * registers 15 at a time. */
+     * registers 10 at a time. */
     float* xs = L.sm;
     for (int j = lane; j < mlen + N; j += WAVE) xs[j] = buf[j] * sf;
     LSYNC();
@@ -362,12 +370,12 @@ STAGE void st_resample(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
         if (!on0) b0 = xs;                            /* idle lanes read in bounds */
         if (!on1) b1 = xs;
         float m0 = 0, m1 = 0;
-        for (int tb = 0; tb < T; tb += 15) {          /* T = 30, 60 or 120; 15 taps at a time keeps the stage inside its register budget */
-            float tap[15];
+        for (int tb = 0; tb < T; tb += 10) {          /* T = 240 / stride = 10 ... 120; 10 taps at a time keep the stage inside its register budget */
+            float tap[10];
 #pragma unroll
-            for (int m = 0; m < 15; m++) tap[m] = tp[tb + m];
+            for (int m = 0; m < 10; m++) tap[m] = tp[tb + m];
 #pragma unroll
-            for (int m = 0; m < 15; m++) { m0 += b0[tb + m] * tap[m]; m1 += b1[tb + m] * tap[m]; }
+            for (int m = 0; m < 10; m++) { m0 += b0[tb + m] * tap[m]; m1 += b1[tb + m] * tap[m]; }
         }
         d[0] = on0 ? m0 : 0.0f; d[1] = on1 ? m1 : 0.0f;
     }
@@ -763,39 +771,80 @@ STAGE void mdct_dft240_rows(WaveLds& L, int lane)   /* 16 transforms of length 1
     }
     LSYNC();
 }
-STAGE void mdct_dft120(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)   /* 8 x 3 x 5 prime-factor DFT, X -> A */
+/* Prime-factor DFT of N/2 in {10, 20, 30, 40, 80, 120} (R/fft/fft_generic.h:634-699 pfaDFT with fft_n leaves): two or three
+ * stages of small DFTs whose gather maps the host derived by running the reference's index logic on slot labels.  One lane per
+ * small transform; a stage reads its inputs, the wave synchronises, then writes consecutive slots, so it may work in place.
+ * X -> (X ->) A, the last stage scattering to natural order. */
+__device__ __forceinline__ void pfa_stage(const uint8_t* __restrict__ map, const uint8_t* __restrict__ dst, const float* in, float* out, int rad, int cnt, int lane)
 {
-    float* X = XCUR(L);
-    const uint8_t* m1 = P->pfa_src; const uint8_t* m2 = P->pfa_src + 120; const uint8_t* m3 = P->pfa_src + 240;
-    if (lane < 15) {
-        float v[16];
+    float v[32];
+    const bool on = lane < cnt;
+    const int base = on ? lane * rad : 0;
 #pragma unroll
-        for (int j = 0; j < 8; j++) { const int s = m1[lane * 8 + j]; v[2 * j] = X[2 * s]; v[2 * j + 1] = X[2 * s + 1]; }
-        dft8(v);
-#pragma unroll
-        for (int j = 0; j < 8; j++) { const int d = lane * 8 + j; L.A[2 * d] = v[2 * j]; L.A[2 * d + 1] = v[2 * j + 1]; }
+    for (int j = 0; j < 16; j++) if (j < rad) { const int s = map[base + j]; v[2 * j] = in[2 * s]; v[2 * j + 1] = in[2 * s + 1]; }
+    switch (rad) {
+    case 2: { const float r1 = v[0], i1 = v[1], r2 = v[2], i2 = v[3]; v[0] = r1 + r2; v[1] = i1 + i2; v[2] = r1 - r2; v[3] = i1 - i2; } break;   /* R/fft/fft_2_9.h:22-37 */
+    case 3: dft3(v); break;
+    case 4: dft4(v); break;
+    case 5: dft5(v); break;
+    case 8: dft8(v); break;
+    default: dft16(v); break;
     }
     LSYNC();
-    if (lane < 40) {
-        float v[6];
+    if (on) {
 #pragma unroll
-        for (int j = 0; j < 3; j++) { const int s = m2[lane * 3 + j]; v[2 * j] = L.A[2 * s]; v[2 * j + 1] = L.A[2 * s + 1]; }
-        dft3(v);
-#pragma unroll
-        for (int j = 0; j < 3; j++) { const int d = lane * 3 + j; X[2 * d] = v[2 * j]; X[2 * d + 1] = v[2 * j + 1]; }
-    }
-    LSYNC();
-    if (lane < 24) {
-        float v[10];
-#pragma unroll
-        for (int j = 0; j < 5; j++) { const int s = m3[lane * 5 + j]; v[2 * j] = X[2 * s]; v[2 * j + 1] = X[2 * s + 1]; }
-        dft5(v);
-#pragma unroll
-        for (int j = 0; j < 5; j++) { const int d = P->pfa_dst[lane * 5 + j]; L.A[2 * d] = v[2 * j]; L.A[2 * d + 1] = v[2 * j + 1]; }
+        for (int j = 0; j < 16; j++) if (j < rad) { const int d = dst ? dst[base + j] : base + j; out[2 * d] = v[2 * j]; out[2 * d + 1] = v[2 * j + 1]; }
     }
     LSYNC();
 }
-/* window + fold + memory slide + pre-twiddle (leaf stage) */
+STAGE void mdct_dft_pfa(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
+{
+    float* X = XCUR(L);
+    const int len = PI(N) >> 1, nst = PI(pfa_nst);
+    const int r0 = PI(pfa_rad[0]), r1 = PI(pfa_rad[1]), r2 = PI(pfa_rad[2]);
+    if (nst == 3) {
+        pfa_stage(P->pfa_src, nullptr, X, L.A, r0, len / r0, lane);
+        pfa_stage(P->pfa_src + 120, nullptr, L.A, X, r1, len / r1, lane);
+        pfa_stage(P->pfa_src + 240, P->pfa_dst, X, L.A, r2, len / r2, lane);
+    } else {
+        pfa_stage(P->pfa_src, nullptr, X, X, r0, len / r0, lane);
+        pfa_stage(P->pfa_src + 120, P->pfa_dst, X, L.A, r1, len / r1, lane);
+    }
+}
+
+/* 60 = 4 x 15 Good-Thomas (R/fft/fft_60_128.h:16-66): four 15-point transforms in place over the map (45k + 16l) % 60, then
+ * fifteen 4-point transforms scattering to (15k + 4l) % 60.  X -> A. */
+STAGE void mdct_dft60(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
+{
+    float* X = XCUR(L);
+    const uint8_t* m = P->pfa_src;                  /* m[k + 4 l] = (45k + 16l) % 60 */
+    {
+        float v[30];
+        const int k = lane < 4 ? lane : 0;
+#pragma unroll
+        for (int l = 0; l < 15; l++) { const int s = m[k + 4 * l]; v[2 * l] = X[2 * s]; v[2 * l + 1] = X[2 * s + 1]; }
+        dft15(v);
+        LSYNC();
+        if (lane < 4) {
+#pragma unroll
+            for (int l = 0; l < 15; l++) { const int s = m[k + 4 * l]; X[2 * s] = v[2 * l]; X[2 * s + 1] = v[2 * l + 1]; }
+        }
+        LSYNC();
+    }
+    {
+        float v[8];
+        const int l = lane < 15 ? lane : 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { const int s = m[k + 4 * l]; v[2 * k] = X[2 * s]; v[2 * k + 1] = X[2 * s + 1]; }
+        dft4(v);
+        if (lane < 15) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const int d = P->pfa_dst[k + 4 * l]; L.A[2 * d] = v[2 * k]; L.A[2 * d + 1] = v[2 * k + 1]; }
+        }
+        LSYNC();
+    }
+}
+
 STAGE void mdct_pre(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
 {
     const int N = PI(N), h = N >> 1, la = PI(la), ml = N - la;
@@ -2235,7 +2284,7 @@ lc3_encode_kernel(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__
     const int lane = threadIdx.x;
     const int cs = blockIdx.x;
     if (cs >= ncs) return;
-    if (lane < 42) L.pc[lane] = ((const int*)P)[lane];
+    if (lane < LC3D_PLAN_HEAD_WORDS) L.pc[lane] = ((const int*)P)[lane];
     if (lane < 14) L.cc[lane] = ((const int*)&chans[cs])[lane];
     LSYNC();
     const lc3d_chan* __restrict__ C = &chans[cs];
@@ -2296,7 +2345,9 @@ lc3_encode_kernel(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__
         if (CI(attack_handling)) st_attack(P, L, lane);
         TICK(5);
         mdct_pre(P, L, lane);
-        if (PI(N) == 480) { mdct_dft240_cols(L, lane); mdct_dft240_rows(L, lane); } else mdct_dft120(P, L, lane);
+        if (PI(N) == 480) { mdct_dft240_cols(L, lane); mdct_dft240_rows(L, lane); }
+        else if (PI(N) == 120) mdct_dft60(P, L, lane);
+        else mdct_dft_pfa(P, L, lane);
         mdct_post(P, L, lane);
         TICK(1);
         if (tr) for (int i = lane; i < N; i += WAVE) tr->spec_mdct[i] = L.A[i];

@@ -68,7 +68,7 @@ struct lc3o_enc {
     cpx dct2_tw[16];
     double idct_cos[16][16];
     float sns_preemph[64];
-    int fft_kind;    /* 240, 120, 0 = unsupported */
+    int fft_kind;    /* N/2 when a DFT kernel of that length is restated (lc3_oracle_fft.inc dft_any), 0 = unsupported */
     lc3o_trace* trace;
     chan_t ch[LC3O_MAX_CH];
 };
@@ -115,7 +115,7 @@ static void frame_params(lc3o_enc* e)
         e->tw2[i] = cexpi_f(-M_PI * i / len);
     }
     e->dct4_norm = 1.0 / sqrtf(len / 2);                       /* R/dct4.c:82 */
-    if (len / 2 == 240) e->fft_kind = 240; else if (len / 2 == 120) e->fft_kind = 120;
+    { const int h = len / 2; e->fft_kind = (h == 10 || h == 20 || h == 30 || h == 40 || h == 60 || h == 80 || h == 120 || h == 240) ? h : 0; }
     /* DCT-II(16) post-twiddle: R/dct4.c:43-45 */
     for (int i = 0; i < 16; i++) {
         cpx s = {2 / sqrtf(2 * 16), 0};
@@ -278,9 +278,7 @@ static void stage_mdct(const lc3o_enc* e, chan_t* s, const float* in, float* out
         cpx c = cmul_f(a, e->tw1[i]);
         z[2 * i] = c.r; z[2 * i + 1] = c.i;
     }
-    if (e->fft_kind == 240) dft240(z);
-    else if (e->fft_kind == 120) { static const int f[3] = {8, 3, 5}; dft_pfa(z, 120, scratch, 3, f); }
-    else assert(!"unsupported transform length");
+    if (!dft_any(z, h, scratch)) assert(!"unsupported transform length");
     for (int i = 0; i < h; i++) {
         cpx a = {z[2 * i], z[2 * i + 1]};
         cpx t = cmul_f(a, e->tw2[i]);

@@ -59,6 +59,20 @@ def test_golden_stereo():
     (48000, 10.0, 1, 480, [128000, 256000, 400000, 500000] * 2),
     (48000, 5.0, 1, 240, [160000, 320000, 600000] * 2),
     (44100, 10.0, 0, 480, [32000, 64000, 128000, 256000] * 2),
+    # the other sample rates / frame lengths (N/2-point DFT by prime factors or 4 x 15): SURVEY 8f-4
+    (8000, 10.0, 0, 80, [16000, 24000, 32000, 64000] * 2),
+    (16000, 10.0, 0, 160, [16000, 32000, 64000, 128000] * 2),
+    (16000, 5.0, 0, 80, [32000, 64000, 96000, 128000] * 2),
+    (16000, 2.5, 0, 40, [64000, 96000, 128000, 192000] * 2),
+    (8000, 5.0, 0, 40, [32000, 48000, 64000, 96000] * 2),
+    (8000, 2.5, 0, 20, [64000, 96000, 128000, 160000] * 2),
+    (24000, 5.0, 0, 120, [32000, 64000, 96000, 160000] * 2),
+    (24000, 2.5, 0, 60, [64000, 96000, 128000, 256000] * 2),
+    (32000, 5.0, 0, 160, [32000, 64000, 96000, 192000] * 2),
+    (32000, 2.5, 0, 80, [64000, 96000, 128000, 256000] * 2),
+    (48000, 2.5, 0, 120, [64000, 96000, 128000, 320000] * 2),
+    (44100, 5.0, 0, 240, [64000, 128000] * 2),
+    (48000, 2.5, 1, 120, [172800, 256000, 400000] * 2),
 ])
 def test_vs_oracle_same_math(fs, ms, hr, N, rates):
     B, T = len(rates), 24

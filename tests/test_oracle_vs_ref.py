@@ -71,6 +71,20 @@ def test_api_error_codes_match():
     (48000, 10.0, 1, 480, [128000, 256000, 400000]),
     (48000, 5.0, 1, 240, [160000, 320000]),
     (44100, 10.0, 0, 480, [32000, 64000, 128000]),
+    (8000, 10.0, 0, 80, [16000, 32000, 64000]),
+    (16000, 10.0, 0, 160, [16000, 32000, 64000, 128000]),
+    (16000, 5.0, 0, 80, [32000, 64000, 128000]),
+    (16000, 2.5, 0, 40, [64000, 96000, 192000]),
+    (8000, 5.0, 0, 40, [32000, 64000, 96000]),
+    (8000, 2.5, 0, 20, [64000, 96000, 160000]),
+    (24000, 5.0, 0, 120, [32000, 64000, 160000]),
+    (24000, 2.5, 0, 60, [64000, 96000, 256000]),
+    (32000, 5.0, 0, 160, [32000, 64000, 192000]),
+    (32000, 2.5, 0, 80, [64000, 96000, 256000]),
+    (48000, 2.5, 0, 120, [64000, 128000, 320000]),
+    (44100, 5.0, 0, 240, [64000, 128000]),
+    (44100, 2.5, 0, 120, [96000]),
+    (48000, 2.5, 1, 120, [172800, 256000, 400000]),
 ])
 def test_other_geometries(fs, ms, hr, N, rates):
     pcm = synth_pcm(len(rates), 40, N, fs if fs != 44100 else 48000, seed=13)
