@@ -66,7 +66,7 @@ static void geom_update(geom_t* g)                                        /* R/s
 }
 
 /* the kernels are built for frame lengths up to LC3D_MAX_N whose N/2-point DFT has a restated kernel (240 = 15x16, 60 = 4x15, and
- * the prime-factor lengths 10, 20, 30, 40, 80, 120; not 160 = 32x5 of 32 kHz / 10 ms, not 480) and an MDCT overlap memory of at
+ * the prime-factor lengths 10, 20, 30, 40, 80, 120, 160; not 480) and an MDCT overlap memory of at
  * most 300 samples (excludes 96 kHz / 5 ms: N = 480 with 120 leading zeros) */
 static int fft_supported(int len);
 static int geom_supported(const geom_t* g) { return g->tab && g->N <= LC3D_MAX_N && fft_supported(g->N / 2) && g->N - g->la <= 300; }
@@ -165,16 +165,16 @@ static void pfa_label(int* x, int length, int* scratch, int nfac, const int* fac
 static int pfa_plan(lc3d_plan* p, int len)
 {
     static const struct { int len, n, f[3]; } tab[] = {{10, 2, {2, 5, 0}}, {20, 2, {4, 5, 0}}, {30, 3, {2, 3, 5}}, {40, 2, {8, 5, 0}},
-                                                        {80, 2, {16, 5, 0}}, {120, 3, {8, 3, 5}}};
+                                                        {80, 2, {16, 5, 0}}, {120, 3, {8, 3, 5}}, {160, 2, {32, 5, 0}}};
     if (len == 60) {                                /* 4 x 15 Good-Thomas with the reference's index tables (R/fft/fft_60_128.h:18-23) */
         for (int k = 0; k < 4; k++) for (int l = 0; l < 15; l++) { p->pfa_src[k + 4 * l] = (uint8_t)((45 * k + 16 * l) % 60); p->pfa_dst[k + 4 * l] = (uint8_t)((15 * k + 4 * l) % 60); }
         p->pfa_nst = 0;
         return 1;
     }
     for (unsigned t = 0; t < sizeof tab / sizeof tab[0]; t++) if (tab[t].len == len) {
-        int x[120], scratch[240];
+        int x[LC3D_PFA_STRIDE], scratch[2 * LC3D_PFA_STRIDE];
         pfa_rec r; memset(&r, 0, sizeof r);
-        for (int k = 0; k < 3; k++) { r.src[k] = p->pfa_src + 120 * k; r.leaf[k] = tab[t].f[k]; p->pfa_rad[k] = tab[t].f[k]; }
+        for (int k = 0; k < 3; k++) { r.src[k] = p->pfa_src + LC3D_PFA_STRIDE * k; r.leaf[k] = tab[t].f[k]; p->pfa_rad[k] = tab[t].f[k]; }
         p->pfa_nst = tab[t].n;
         for (int i = 0; i < len; i++) x[i] = i;
         pfa_label(x, len, scratch, tab[t].n, tab[t].f, &r);
@@ -184,7 +184,7 @@ static int pfa_plan(lc3d_plan* p, int len)
     }
     return 0;
 }
-static int fft_supported(int len) { return len == 240 || len == 60 || len == 10 || len == 20 || len == 30 || len == 40 || len == 80 || len == 120; }
+static int fft_supported(int len) { return len == 240 || len == 60 || len == 10 || len == 20 || len == 30 || len == 40 || len == 80 || len == 120 || len == 160; }
 
 /* R/util.h:109 cexpi with the reference's float argument conversion */
 static void cexpi_f(float x, float* re, float* im) { *re = cosf(x); *im = sinf(x); }

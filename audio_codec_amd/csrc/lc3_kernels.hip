@@ -688,10 +688,10 @@ STAGE void st_attack(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
 /* One half of the 16-point kernel (R/fft/fft_15_16.h:214-401): ODD = false produces the 8 even-indexed outputs from the sums
  * E[i] = v[i] + v[i+16], ODD = true the 8 odd-indexed outputs from the differences O[i].  Operation for operation identical to
  * dft16(); splitting it lets two lanes share one transform (half the registers, half the latency). */
+__device__ __forceinline__ void dft16_oddblock(const float* O, float* o);
 template <bool ODD> __device__ __forceinline__ void dft16_half(const float* v, float* o /* 8 complex outputs: k = ODD + 2j */)
 {
-    const float S = 7.071067811865475e-1f, C1 = 9.238795325112867e-1f, C3 = 3.826834323650898e-1f;
-    const float SP = 2.414213562373095f, SM = 4.142135623730952e-1f;
+    const float S = 7.071067811865475e-1f;
     if (!ODD) {
         float E[16], P[16], Q[16];
 #pragma unroll
@@ -718,6 +718,16 @@ template <bool ODD> __device__ __forceinline__ void dft16_half(const float* v, f
         float O[16];
 #pragma unroll
         for (int i = 0; i < 16; i++) O[i] = v[i] - v[i + 16];
+        dft16_oddblock(O, o);
+    }
+}
+/* odd half of the 16-point kernel on 8 complex differences O (R/fft/fft_15_16.h:289-372; the same block is the "fft8even" part of
+ * the 32-point kernel, R/fft/fft_32.h:330-412): o[m] = bin 2m+1 */
+__device__ __forceinline__ void dft16_oddblock(const float* O, float* o)
+{
+    const float S = 7.071067811865475e-1f, C1 = 9.238795325112867e-1f, C3 = 3.826834323650898e-1f;
+    const float SP = 2.414213562373095f, SM = 4.142135623730952e-1f;
+    {
         float g9 = (O[2] + O[14]) * -C3, g10 = (O[2] - O[14]) * C1, g8 = (O[3] + O[15]) * C3, g11 = (O[3] - O[15]) * C1;
         const float g5 = (O[4] + O[12]) * -S,  g6 = (O[4] - O[12]) * S,   g4 = (O[5] + O[13]) * S,  g7 = (O[5] - O[13]) * S;
         const float g13 = (O[6] + O[10]) * -C1, g14 = (O[6] - O[10]) * C3, g12 = (O[7] + O[11]) * C1, g15 = (O[7] - O[11]) * C3;
@@ -771,10 +781,79 @@ STAGE void mdct_dft240_rows(WaveLds& L, int lane)   /* 16 transforms of length 1
     }
     LSYNC();
 }
-/* Prime-factor DFT of N/2 in {10, 20, 30, 40, 80, 120} (R/fft/fft_generic.h:634-699 pfaDFT with fft_n leaves): two or three
+/* Prime-factor DFT of N/2 in {10, 20, 30, 40, 80, 120, 160} (R/fft/fft_generic.h:634-699 pfaDFT with fft_n leaves): two or three
  * stages of small DFTs whose gather maps the host derived by running the reference's index logic on slot labels.  One lane per
  * small transform; a stage reads its inputs, the wave synchronises, then writes consecutive slots, so it may work in place.
  * X -> (X ->) A, the last stage scattering to natural order. */
+/* 32-point kernel (R/fft/fft_32.h:16-467) split over two lanes: with s_k = x_k + x_{k+16}, d_k = x_k - x_{k+16}, the even bins are the
+ * 16-point kernel on s (lane 0 of the pair); odd bin 2m+1 = T_m + F_m and bin 2m+17 = T_m - F_m, T = odd block of the 16-point kernel on
+ * (d_0, d_2, .., d_14), F = the 4x4 rotations of (d_1, d_3, .., d_15) (lane 1).  sd: 16 complex sums or differences; o: 16 complex bins. */
+template <bool ODD> __device__ __forceinline__ void dft32_half(float* sd, float* o)
+{
+    if (!ODD) {
+        dft16(sd);
+#pragma unroll
+        for (int i = 0; i < 32; i++) o[i] = sd[i];
+    } else {
+        const float c0 = 9.807852804032304e-1f, c1 = 8.314696123025452e-1f, c2 = 5.555702330196023e-1f, c3 = 1.950903220161283e-1f;
+        float de[16], T[16], A[4], B[4], C[4], D[4];
+#pragma unroll
+        for (int j = 0; j < 8; j++) { de[2 * j] = sd[4 * j]; de[2 * j + 1] = sd[4 * j + 1]; }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {               /* pairs (d_{2j+1}, d_{15-2j}) */
+            const float er = sd[4 * j + 2], ei = sd[4 * j + 3], fr = sd[4 * (7 - j) + 2], fi = sd[4 * (7 - j) + 3];
+            B[j] = -(er + fr); C[j] = er - fr; A[j] = ei + fi; D[j] = ei - fi;
+        }
+        const float a0 = A[0] * c3 + A[1] * c2 + A[2] * c1 + A[3] * c0, a1 = A[0] * c2 + A[1] * c0 + A[2] * c3 - A[3] * c1;
+        const float a2 = A[0] * c1 + A[1] * c3 - A[2] * c0 + A[3] * c2, a3 = A[0] * c0 - A[1] * c1 + A[2] * c2 - A[3] * c3;
+        const float b0 = B[0] * c3 + B[1] * c2 + B[2] * c1 + B[3] * c0, b1 = B[0] * c2 + B[1] * c0 + B[2] * c3 - B[3] * c1;
+        const float b2 = B[0] * c1 + B[1] * c3 - B[2] * c0 + B[3] * c2, b3 = B[0] * c0 - B[1] * c1 + B[2] * c2 - B[3] * c3;
+        const float g0 = C[0] * c0 + C[1] * c1 + C[2] * c2 + C[3] * c3, g1 = C[0] * c1 - C[1] * c3 - C[2] * c0 - C[3] * c2;
+        const float g2 = C[0] * c2 - C[1] * c0 + C[2] * c3 + C[3] * c1, g3 = C[0] * c3 - C[1] * c2 + C[2] * c1 - C[3] * c0;
+        const float h0 = D[0] * c0 + D[1] * c1 + D[2] * c2 + D[3] * c3, h1 = D[0] * c1 - D[1] * c3 - D[2] * c0 - D[3] * c2;
+        const float h2 = D[0] * c2 - D[1] * c0 + D[2] * c3 + D[3] * c1, h3 = D[0] * c3 - D[1] * c2 + D[2] * c1 - D[3] * c0;
+        float F[16];
+        F[0] = a0 + g0;  F[1] = b0 + h0;   F[14] = a0 - g0; F[15] = b0 - h0;
+        F[2] = a1 + g1;  F[3] = b1 + h1;   F[12] = a1 - g1; F[13] = b1 - h1;
+        F[4] = a2 + g2;  F[5] = b2 + h2;   F[10] = a2 - g2; F[11] = b2 - h2;
+        F[6] = a3 + g3;  F[7] = b3 + h3;   F[8] = a3 - g3;  F[9] = b3 - h3;
+        dft16_oddblock(de, T);
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+            o[2 * m] = T[2 * m] + F[2 * m];        o[2 * m + 1] = T[2 * m + 1] + F[2 * m + 1];          /* bin 2m+1  */
+            o[16 + 2 * m] = T[2 * m] - F[2 * m];   o[16 + 2 * m + 1] = T[2 * m + 1] - F[2 * m + 1];     /* bin 2m+17 */
+        }
+    }
+}
+/* first stage of the 160-point prime-factor DFT: five 32-point transforms, two lanes each; in place with a barrier */
+__device__ __forceinline__ void pfa_stage32(const uint8_t* __restrict__ map, const float* in, float* out, int cnt, int lane)
+{
+    const bool on = lane < 2 * cnt;
+    const int t = on ? lane >> 1 : 0, half = lane & 1;
+    float sd[32], o[32];
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int sa = map[t * 32 + k], sb = map[t * 32 + k + 16];
+        const float ar = in[2 * sa], ai = in[2 * sa + 1], br = in[2 * sb], bi = in[2 * sb + 1];
+        sd[2 * k] = half ? ar - br : ar + br; sd[2 * k + 1] = half ? ai - bi : ai + bi;
+    }
+    if (half) dft32_half<true>(sd, o); else dft32_half<false>(sd, o);
+    LSYNC();
+    if (on) {
+        if (!half) {
+#pragma unroll
+            for (int m = 0; m < 16; m++) { const int d = t * 32 + 2 * m; out[2 * d] = o[2 * m]; out[2 * d + 1] = o[2 * m + 1]; }
+        } else {
+#pragma unroll
+            for (int m = 0; m < 8; m++) {
+                const int d = t * 32 + 2 * m + 1;
+                out[2 * d] = o[2 * m]; out[2 * d + 1] = o[2 * m + 1];
+                out[2 * (d + 16)] = o[16 + 2 * m]; out[2 * (d + 16) + 1] = o[16 + 2 * m + 1];
+            }
+        }
+    }
+    LSYNC();
+}
 __device__ __forceinline__ void pfa_stage(const uint8_t* __restrict__ map, const uint8_t* __restrict__ dst, const float* in, float* out, int rad, int cnt, int lane)
 {
     float v[32];
@@ -804,11 +883,12 @@ STAGE void mdct_dft_pfa(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
     const int r0 = PI(pfa_rad[0]), r1 = PI(pfa_rad[1]), r2 = PI(pfa_rad[2]);
     if (nst == 3) {
         pfa_stage(P->pfa_src, nullptr, X, L.A, r0, len / r0, lane);
-        pfa_stage(P->pfa_src + 120, nullptr, L.A, X, r1, len / r1, lane);
-        pfa_stage(P->pfa_src + 240, P->pfa_dst, X, L.A, r2, len / r2, lane);
+        pfa_stage(P->pfa_src + LC3D_PFA_STRIDE, nullptr, L.A, X, r1, len / r1, lane);
+        pfa_stage(P->pfa_src + 2 * LC3D_PFA_STRIDE, P->pfa_dst, X, L.A, r2, len / r2, lane);
     } else {
-        pfa_stage(P->pfa_src, nullptr, X, X, r0, len / r0, lane);
-        pfa_stage(P->pfa_src + 120, P->pfa_dst, X, L.A, r1, len / r1, lane);
+        if (r0 == 32) pfa_stage32(P->pfa_src, X, X, len / 32, lane);
+        else pfa_stage(P->pfa_src, nullptr, X, X, r0, len / r0, lane);
+        pfa_stage(P->pfa_src + LC3D_PFA_STRIDE, P->pfa_dst, X, L.A, r1, len / r1, lane);
     }
 }
 

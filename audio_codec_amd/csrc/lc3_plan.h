@@ -13,6 +13,7 @@
 #include <stdint.h>
 
 #define LC3D_MAX_N 480          /* largest frame length built so far (48 kHz / 10 ms, 96 kHz / 2.5-5 ms) */
+#define LC3D_PFA_STRIDE 160     /* longest prime-factor DFT (32 kHz / 10 ms: 160 = 32 x 5) */
 #define LC3D_GAIN_TAB 512       /* gain index k = ind + gg_off in [-256, 255] -> tab[k + 256] */
 
 typedef struct {
@@ -29,7 +30,7 @@ typedef struct {
     float   c_idct_n1, c_idct_n2;   /* R/sns_quantize_scf.c:24-25 */
     float   c_thr7_up;          /* smallest float >= (7.0)*(28.0/20.0):  (double)t < thr  <=>  t < c_thr7_up  (R/estimate_global_gain.c:106) */
     float   c_thr50_dn;         /* largest float <= (50.0)*(28.0/20.0): (double)t > thr  <=>  t > c_thr50_dn (R/estimate_global_gain.c:111) */
-    int32_t pfa_nst;            /* prime-factor DFT stages (2 or 3) for N/2 in {10,20,30,40,80,120}; 0: N/2 = 240 or 60 use their own kernels */
+    int32_t pfa_nst;            /* prime-factor DFT stages (2 or 3) for N/2 in {10,20,30,40,80,120,160}; 0: N/2 = 240 or 60 use their own kernels */
     int32_t pfa_rad[3];         /* stage radices (leaf DFT lengths), in execution order */
     float   pad0;
     float   tw1[LC3D_MAX_N], tw2[LC3D_MAX_N];      /* N/2 complex (re,im) pairs each */
@@ -40,8 +41,8 @@ typedef struct {
     float   rs_taps[240];                          /* 12.8 kHz resampler low-pass, phase-major: [start][m] = lp[239 - start - m*stride] (R/resamp12k8.c:48-57) */
     double  idct_cos[256];
     uint8_t band_of_bin[LC3D_MAX_N];
-    uint8_t pfa_src[360];       /* prime-factor DFT: gather maps of up to three stages (120 entries each); for N/2 = 60: [0..59] = (45k+16l)%60 */
-    uint8_t pfa_dst[120];       /* scatter of the last stage; for N/2 = 60: (15k+4l)%60 */
+    uint8_t pfa_src[3 * LC3D_PFA_STRIDE];   /* prime-factor DFT: gather maps of up to three stages; for N/2 = 60: [0..59] = (45k+16l)%60 */
+    uint8_t pfa_dst[LC3D_PFA_STRIDE];       /* scatter of the last stage; for N/2 = 60: (15k+4l)%60 */
 } lc3d_plan;
 #define LC3D_PLAN_HEAD_WORDS 45     /* the scalar head (up to and including pad0) that every wave copies into LDS */
 

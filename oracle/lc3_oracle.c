@@ -115,7 +115,7 @@ static void frame_params(lc3o_enc* e)
         e->tw2[i] = cexpi_f(-M_PI * i / len);
     }
     e->dct4_norm = 1.0 / sqrtf(len / 2);                       /* R/dct4.c:82 */
-    { const int h = len / 2; e->fft_kind = (h == 10 || h == 20 || h == 30 || h == 40 || h == 60 || h == 80 || h == 120 || h == 240) ? h : 0; }
+    { const int h = len / 2; e->fft_kind = (h == 10 || h == 20 || h == 30 || h == 40 || h == 60 || h == 80 || h == 120 || h == 160 || h == 240) ? h : 0; }
     /* DCT-II(16) post-twiddle: R/dct4.c:43-45 */
     for (int i = 0; i < 16; i++) {
         cpx s = {2 / sqrtf(2 * 16), 0};
@@ -1333,3 +1333,6 @@ int lc3o_encode_batch16(int samplerate, float frame_ms, int hrmode, int B, int T
     free(e);
     return rc;
 }
+
+/* test hook: the restated forward DFT on its own (tests/test_oracle_vs_ref.py pins it against the reference's LC3_iisfft_apply) */
+int lc3o_dft(float* x, int n) { float scratch[2 * LC3O_MAX_N]; return dft_any(x, n, scratch); }

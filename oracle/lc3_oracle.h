@@ -68,6 +68,7 @@ void lc3o_enc_free(lc3o_enc* e);
 
 /* Convenience for tests / CPU baseline: B independent MONO streams, T frames each.
  * pcm[B][T][N] int16, out[B][T][stride]; per-stream bitrate; returns 0 or an error code. */
+int  lc3o_dft(float* x, int n);      /* test hook: forward complex DFT of length n in place (interleaved re, im); 0 = no kernel */
 int  lc3o_encode_batch16(int samplerate, float frame_ms, int hrmode, int B, int T, const int* bitrate,
                          const int16_t* pcm, uint8_t* out, int stride);
 

@@ -68,6 +68,7 @@ def test_golden_stereo():
     (8000, 2.5, 0, 20, [64000, 96000, 128000, 160000] * 2),
     (24000, 5.0, 0, 120, [32000, 64000, 96000, 160000] * 2),
     (24000, 2.5, 0, 60, [64000, 96000, 128000, 256000] * 2),
+    (32000, 10.0, 0, 320, [32000, 64000, 96000, 128000, 192000, 320000] * 2),
     (32000, 5.0, 0, 160, [32000, 64000, 96000, 192000] * 2),
     (32000, 2.5, 0, 80, [64000, 96000, 128000, 256000] * 2),
     (48000, 2.5, 0, 120, [64000, 96000, 128000, 320000] * 2),

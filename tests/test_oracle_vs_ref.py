@@ -1,5 +1,7 @@
 """CPU, build container only: the oracle restatement against the live compiled ETSI reference (oracle/_ref).
 Skipped where oracle/_ref is absent; the committed golden vectors cover that case."""
+import os
+
 import numpy as np
 import pytest
 from lc3_harness import Oracle, Ref, have_ref, oracle_encode_streams, ref_encode_streams, synth_pcm
@@ -79,6 +81,7 @@ def test_api_error_codes_match():
     (8000, 2.5, 0, 20, [64000, 96000, 160000]),
     (24000, 5.0, 0, 120, [32000, 64000, 160000]),
     (24000, 2.5, 0, 60, [64000, 96000, 256000]),
+    (32000, 10.0, 0, 320, [32000, 64000, 96000, 192000, 320000]),
     (32000, 5.0, 0, 160, [32000, 64000, 192000]),
     (32000, 2.5, 0, 80, [64000, 96000, 256000]),
     (48000, 2.5, 0, 120, [64000, 128000, 320000]),
@@ -90,3 +93,22 @@ def test_other_geometries(fs, ms, hr, N, rates):
     pcm = synth_pcm(len(rates), 40, N, fs if fs != 44100 else 48000, seed=13)
     for r, o in zip(ref_encode_streams(pcm, fs, ms, hr, rates), oracle_encode_streams(pcm, fs, ms, hr, rates)):
         assert (r == o).all()
+
+
+@pytest.mark.parametrize("n", [2, 3, 4, 5, 8, 15, 16, 32, 10, 20, 30, 40, 60, 80, 120, 160, 240])
+def test_dft_kernels_match_the_reference_fft(n):
+    """The restated DFT kernels (oracle/lc3_oracle_fft.inc) against LC3_iisfft_apply of the compiled reference, bit for bit."""
+    import ctypes as C
+    from lc3_harness import ORACLE_DIR
+    ref = C.CDLL(os.path.join(ORACLE_DIR, "_ref", "liblc3_etsi_fl.so")); orc = C.CDLL(os.path.join(ORACLE_DIR, "liblc3_oracle.so"))
+    ref.LC3_iisfft_plan.argtypes = [C.c_void_p, C.c_int, C.c_int]; ref.LC3_iisfft_apply.argtypes = [C.c_void_p, C.c_void_p]
+    orc.lc3o_dft.argtypes = [C.c_void_p, C.c_int]
+    h = C.create_string_buffer(512)
+    assert ref.LC3_iisfft_plan(h, n, -1) == 0
+    rng = np.random.default_rng(n)
+    for _ in range(100):
+        x = (rng.standard_normal(2 * n) * rng.choice([1, 1e3, 1e-3, 32768])).astype(np.float32)
+        a, b = x.copy(), x.copy()
+        ref.LC3_iisfft_apply(h, a.ctypes.data)
+        assert orc.lc3o_dft(b.ctypes.data, n) == 1
+        assert (a.view(np.uint32) == b.view(np.uint32)).all()
