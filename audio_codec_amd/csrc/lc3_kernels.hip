@@ -825,56 +825,70 @@ template <bool ODD> __device__ __forceinline__ void dft32_half(float* sd, float*
         }
     }
 }
-/* first stage of the 160-point prime-factor DFT: five 32-point transforms, two lanes each; in place with a barrier */
-__device__ __forceinline__ void pfa_stage32(const uint8_t* __restrict__ map, const float* in, float* out, int cnt, int lane)
+/* first stage of the 160-point prime-factor DFT (32 kHz / 10 ms): five 32-point transforms, two lanes each; in place with a barrier.
+ * Its own function: it needs more registers than every other DFT stage. */
+STAGE void mdct_dft160_stage1(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
 {
-    const bool on = lane < 2 * cnt;
+    float* X = XCUR(L);
+    const uint8_t* map = P->pfa_src;
+    const bool on = lane < 10;
     const int t = on ? lane >> 1 : 0, half = lane & 1;
     float sd[32], o[32];
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         const int sa = map[t * 32 + k], sb = map[t * 32 + k + 16];
-        const float ar = in[2 * sa], ai = in[2 * sa + 1], br = in[2 * sb], bi = in[2 * sb + 1];
+        const float ar = X[2 * sa], ai = X[2 * sa + 1], br = X[2 * sb], bi = X[2 * sb + 1];
         sd[2 * k] = half ? ar - br : ar + br; sd[2 * k + 1] = half ? ai - bi : ai + bi;
     }
     if (half) dft32_half<true>(sd, o); else dft32_half<false>(sd, o);
     LSYNC();
     if (on) {
-        if (!half) {
+        /* even lane: o[m] = bin 2m; odd lane: o[m] = bin 2m+1 (m < 8), o[8+m] = bin 2m+17 */
 #pragma unroll
-            for (int m = 0; m < 16; m++) { const int d = t * 32 + 2 * m; out[2 * d] = o[2 * m]; out[2 * d + 1] = o[2 * m + 1]; }
-        } else {
-#pragma unroll
-            for (int m = 0; m < 8; m++) {
-                const int d = t * 32 + 2 * m + 1;
-                out[2 * d] = o[2 * m]; out[2 * d + 1] = o[2 * m + 1];
-                out[2 * (d + 16)] = o[16 + 2 * m]; out[2 * (d + 16) + 1] = o[16 + 2 * m + 1];
-            }
+        for (int m = 0; m < 16; m++) {
+            const int bin = half ? (m < 8 ? 2 * m + 1 : 2 * (m - 8) + 17) : 2 * m;
+            const int d = t * 32 + bin;
+            X[2 * d] = o[2 * m]; X[2 * d + 1] = o[2 * m + 1];
         }
+    }
+    LSYNC();
+}
+template <int RAD> __device__ __forceinline__ void pfa_stage_r(const uint8_t* __restrict__ map, const uint8_t* __restrict__ dst, const float* in, float* out, int cnt, int lane)
+{
+    float v[2 * RAD];
+    const bool on = lane < cnt;
+    const int base = on ? lane * RAD : 0;
+#pragma unroll
+    for (int j = 0; j < RAD; j++) { const int s = map[base + j]; v[2 * j] = in[2 * s]; v[2 * j + 1] = in[2 * s + 1]; }
+    if (RAD == 2) { const float r1 = v[0], i1 = v[1], r2 = v[2], i2 = v[3]; v[0] = r1 + r2; v[1] = i1 + i2; v[2] = r1 - r2; v[3] = i1 - i2; }   /* R/fft/fft_2_9.h:22-37 */
+    else if (RAD == 3) dft3(v);
+    else if (RAD == 4) dft4(v);
+    else if (RAD == 5) dft5(v);
+    else if (RAD == 8) dft8(v);
+    else dft16(v);
+    LSYNC();
+    if (on) {
+#pragma unroll
+        for (int j = 0; j < RAD; j++) { const int d = dst ? dst[base + j] : base + j; out[2 * d] = v[2 * j]; out[2 * d + 1] = v[2 * j + 1]; }
     }
     LSYNC();
 }
 __device__ __forceinline__ void pfa_stage(const uint8_t* __restrict__ map, const uint8_t* __restrict__ dst, const float* in, float* out, int rad, int cnt, int lane)
 {
-    float v[32];
-    const bool on = lane < cnt;
-    const int base = on ? lane * rad : 0;
-#pragma unroll
-    for (int j = 0; j < 16; j++) if (j < rad) { const int s = map[base + j]; v[2 * j] = in[2 * s]; v[2 * j + 1] = in[2 * s + 1]; }
-    switch (rad) {
-    case 2: { const float r1 = v[0], i1 = v[1], r2 = v[2], i2 = v[3]; v[0] = r1 + r2; v[1] = i1 + i2; v[2] = r1 - r2; v[3] = i1 - i2; } break;   /* R/fft/fft_2_9.h:22-37 */
-    case 3: dft3(v); break;
-    case 4: dft4(v); break;
-    case 5: dft5(v); break;
-    case 8: dft8(v); break;
-    default: dft16(v); break;
+    switch (rad) {                                  /* wave-uniform */
+    case 2: pfa_stage_r<2>(map, dst, in, out, cnt, lane); break;
+    case 3: pfa_stage_r<3>(map, dst, in, out, cnt, lane); break;
+    case 4: pfa_stage_r<4>(map, dst, in, out, cnt, lane); break;
+    case 5: pfa_stage_r<5>(map, dst, in, out, cnt, lane); break;
+    default: pfa_stage_r<8>(map, dst, in, out, cnt, lane); break;
     }
-    LSYNC();
-    if (on) {
-#pragma unroll
-        for (int j = 0; j < 16; j++) if (j < rad) { const int d = dst ? dst[base + j] : base + j; out[2 * d] = v[2 * j]; out[2 * d + 1] = v[2 * j + 1]; }
-    }
-    LSYNC();
+}
+/* first stage of the 80-point prime-factor DFT (16 x 5): its own function, so that the 16-point kernel's register needs (and the
+ * callee-saved spills they cause) stay out of the other lengths' path */
+STAGE void mdct_dft80_stage1(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
+{
+    float* X = XCUR(L);
+    pfa_stage_r<16>(P->pfa_src, nullptr, X, X, 5, lane);
 }
 STAGE void mdct_dft_pfa(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
 {
@@ -886,8 +900,7 @@ STAGE void mdct_dft_pfa(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
         pfa_stage(P->pfa_src + LC3D_PFA_STRIDE, nullptr, L.A, X, r1, len / r1, lane);
         pfa_stage(P->pfa_src + 2 * LC3D_PFA_STRIDE, P->pfa_dst, X, L.A, r2, len / r2, lane);
     } else {
-        if (r0 == 32) pfa_stage32(P->pfa_src, X, X, len / 32, lane);
-        else pfa_stage(P->pfa_src, nullptr, X, X, r0, len / r0, lane);
+        if (r0 < 16) pfa_stage(P->pfa_src, nullptr, X, X, r0, len / r0, lane);       /* 16, 32: mdct_dft80_stage1 / mdct_dft160_stage1 have run */
         pfa_stage(P->pfa_src + LC3D_PFA_STRIDE, P->pfa_dst, X, L.A, r1, len / r1, lane);
     }
 }
@@ -2427,7 +2440,7 @@ lc3_encode_kernel(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__
         mdct_pre(P, L, lane);
         if (PI(N) == 480) { mdct_dft240_cols(L, lane); mdct_dft240_rows(L, lane); }
         else if (PI(N) == 120) mdct_dft60(P, L, lane);
-        else mdct_dft_pfa(P, L, lane);
+        else { if (PI(N) == 320) mdct_dft160_stage1(P, L, lane); else if (PI(N) == 160) mdct_dft80_stage1(P, L, lane); mdct_dft_pfa(P, L, lane); }
         mdct_post(P, L, lane);
         TICK(1);
         if (tr) for (int i = lane; i < N; i += WAVE) tr->spec_mdct[i] = L.A[i];
