@@ -230,3 +230,37 @@ def test_cli_switching_files(tmp_path):
         ref = open(theirs, "rb").read()
         assert len(ref) == len(got) and ref[:20] == got[:20]
         assert sum(a != b for a, b in zip(ref, got)) <= 2 * 80      # at most a couple of frames may differ at the libm boundary
+
+
+def _oracle_batch(pcm, fs, ms, hr, rates, stride):
+    """All streams through the oracle's C batch entry (same math as the device), [B, T, stride] uint8."""
+    import ctypes as C
+    from lc3_harness import ORACLE_DIR
+    L = C.CDLL(os.path.join(ORACLE_DIR, "liblc3_oracle_pm.so"))
+    L.lc3o_encode_batch16.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    B, T, N = pcm.shape
+    out = np.zeros((B, T, stride), np.uint8)
+    br = np.asarray(rates, np.int32)
+    pcm = np.ascontiguousarray(pcm)
+    assert L.lc3o_encode_batch16(fs, ms, hr, B, T, br.ctypes.data, pcm.ctypes.data, out.ctypes.data, stride) == 0
+    return out
+
+
+@pytest.mark.parametrize("fs,ms,hr,N,B,T,rates", [
+    (48000, 10.0, 0, 480, 256, 48, [64000]),                       # the metric's configuration: 12 288 frames
+    (48000, 10.0, 0, 480, 192, 32, RATES),                         # mixed bitrates 16-320 kbps (attack detector, LSB mode, LTPF off, LPC weighting)
+    (96000, 2.5, 1, 240, 64, 64, [256000, 198400, 672000, 400000]),
+    (16000, 10.0, 0, 160, 96, 32, [16000, 24000, 32000, 64000]),
+    (32000, 10.0, 0, 320, 64, 32, [32000, 64000, 96000, 128000]),
+])
+def test_large_sweep_vs_oracle(fs, ms, hr, N, B, T, rates):
+    """Thousands of frames per configuration (1 stream in 64 silent, 1 in 64 full-scale noise): the rare paths - a range coder that
+    ends in its carry_count branch, symbol lists longer than one chunk, gain clamps - have to come out identical too."""
+    br = [rates[i % len(rates)] for i in range(B)]
+    pcm = synth_pcm(B, T, N, fs, seed=1009)
+    b = _amd().Batch(B, fs, 1, ms, hr, br, device=0)
+    got = np.concatenate([b.encode(pcm[:, :T // 2]), b.encode(pcm[:, T // 2:])], axis=1)
+    want = _oracle_batch(pcm, fs, ms, hr, br, b.stride)
+    nb = np.array([b.num_bytes(i) for i in range(B)])
+    bad = [(i, t) for i in range(B) for t in range(T) if (got[i, t, :nb[i]] != want[i, t, :nb[i]]).any()]
+    assert not bad, (len(bad), bad[:8])
