@@ -65,11 +65,11 @@ static void geom_update(geom_t* g)                                        /* R/s
     if (g->tab) { g->nbands = g->tab->nbands; g->la = g->tab->la_zeros; }
 }
 
-/* the kernels are built for frame lengths up to LC3D_MAX_N whose N/2-point DFT has a restated kernel (240 = 15x16, 60 = 4x15, and
- * the prime-factor lengths 10, 20, 30, 40, 80, 120, 160; not 480) and an MDCT overlap memory of at
- * most 300 samples (excludes 96 kHz / 5 ms: N = 480 with 120 leading zeros) */
+/* the kernels are built for frame lengths up to LC3D_MAX_N = 960 whose N/2-point DFT has a restated kernel (480 = 15x32, 240 = 15x16,
+ * 60 = 4x15, and the prime-factor lengths 10 ... 160) and an MDCT overlap memory of at most 600 samples: every operating point of
+ * the reference.  N > 480 or a memory > 300 run in the large-layout kernel (lc3_kernels.hip) */
 static int fft_supported(int len);
-static int geom_supported(const geom_t* g) { return g->tab && g->N <= LC3D_MAX_N && fft_supported(g->N / 2) && g->N - g->la <= 300; }
+static int geom_supported(const geom_t* g) { return g->tab && g->N <= LC3D_MAX_N && fft_supported(g->N / 2) && g->N - g->la <= LC3D_MEMCAP_BIG; }
 
 /* R/setup_enc_lc3.c:196-375: bitrate -> per-channel budgets.  Returns an LC3_Error. */
 static LC3_Error derive_bitrate(const geom_t* g, int bitrate, lc3d_chan* ch /* [channels] */)
@@ -184,7 +184,7 @@ static int pfa_plan(lc3d_plan* p, int len)
     }
     return 0;
 }
-static int fft_supported(int len) { return len == 240 || len == 60 || len == 10 || len == 20 || len == 30 || len == 40 || len == 80 || len == 120 || len == 160; }
+static int fft_supported(int len) { return len == 480 || len == 240 || len == 60 || len == 10 || len == 20 || len == 30 || len == 40 || len == 80 || len == 120 || len == 160; }
 
 /* R/util.h:109 cexpi with the reference's float argument conversion */
 static void cexpi_f(float x, float* re, float* im) { *re = cosf(x); *im = sinf(x); }
@@ -238,13 +238,13 @@ static void build_plan(const geom_t* g, lc3d_plan* p)
     memset(p->band_of_bin, 255, sizeof p->band_of_bin);
     const uint16_t* be = &lc3t_band_pool[g->tab->band_off];
     for (int b = 0; b < g->nbands; b++) for (int j = be[b]; j < be[b + 1] && j < LC3D_MAX_N; j++) p->band_of_bin[j] = (uint8_t)b;
-    if (g->N / 2 != 240) pfa_plan(p, g->N / 2);
+    if (g->N / 2 != 240 && g->N / 2 != 480) pfa_plan(p, g->N / 2);
 }
 
-static void init_state(float* st)                                         /* zeroed EncSetup + olpa_mem_pitch = 17 (R/setup_enc_lc3.c:178) */
+static void init_state(float* st, int memcap)                             /* zeroed EncSetup + olpa_mem_pitch = 17 (R/setup_enc_lc3.c:178) */
 {
-    memset(st, 0, sizeof(float) * LC3D_STATE_WORDS);
-    ((int*)st)[LC3D_S_OLPA_PITCH_WORD] = 17;
+    memset(st, 0, sizeof(float) * LC3D_STATE_WORDS(memcap));
+    ((int*)st)[LC3D_S_OLPA_PITCH_WORD(memcap)] = 17;
 }
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -302,9 +302,9 @@ LC3_Error lc3plus_enc_batch_create(lc3plus_batch** out, int n_streams, int sampl
     }
     batch_restride(b);
     lc3d_plan* plan = (lc3d_plan*)malloc(sizeof *plan);
-    float st[LC3D_STATE_WORDS];
+    float st[LC3D_STATE_WORDS_MAX];
     build_plan(&b->g, plan);
-    init_state(st);
+    init_state(st, LC3D_LAYOUT_BIG(b->g.N, b->g.la) ? LC3D_MEMCAP_BIG : LC3D_MEMCAP_STD);
     int rc = lc3hip_create(&b->dev, plan, n_streams, device);
     free(plan);
     if (!rc) rc = lc3hip_reset_state(b->dev, st);

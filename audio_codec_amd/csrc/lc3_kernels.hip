@@ -29,8 +29,23 @@
 #include "lc3_plan.h"
 #include "lc3_shim.h"
 
-#define MAXN LC3D_MAX_N
-#define MEMCAP 300              /* MDCT overlap memory: N - la_zeros <= 300 for every N <= 480 */
+/* Two LDS layouts of the same code.  Standard: frames up to 480 samples with an MDCT memory of at most 300 (every operating
+ * point except two), 10 KB per wave, 4 waves per SIMD.  Large (-DLC3_BIG, kernel lc3_encode_kernel_big): 96 kHz / 10 ms (N = 960)
+ * and 96 kHz / 5 ms (N = 480, MDCT memory 360), 17 KB per wave, 2 waves per SIMD. */
+#ifdef LC3_BIG
+#define MAXN 960
+#define MEMCAP LC3D_MEMCAP_BIG
+#define SMW 1088                /* sm[]: holds the resampler's scaled input (120 + 960 samples) */
+#define KERNEL_NAME lc3_encode_kernel_big
+#define KERNEL_WAVES 2
+#else
+#define MAXN 480
+#define MEMCAP LC3D_MEMCAP_STD  /* MDCT overlap memory: N - la_zeros <= 300 for every N <= 480 except 96 kHz / 5 ms */
+#define SMW 548
+#define KERNEL_NAME lc3_encode_kernel
+#define KERNEL_WAVES 4
+#endif
+#define NQL ((MAXN / 4 + 63) / 64)   /* bisection energies (4 bins each) per lane: 2 or 4 */
 #define WAVE 64
 #define LSYNC() __syncthreads()
 #define STAGE __device__ __attribute__((noinline))
@@ -63,7 +78,7 @@ struct __attribute__((aligned(16))) WaveLds {
     float A[MAXN];              /* scratch, then the MDCT spectrum (shaped / TNS-filtered in place); the output frame during the bitstream stage */
     float h12[384];             /* HP-filtered 12.8 kHz stream, newest sample at [383] */
     float h6[194];              /* 6.4 kHz stream, newest at [193] */
-    float sm[548];              /* small vectors (SM_*); from quantisation on: cdw[240] | residual / LSB bits (160 words) */
+    float sm[SMW];              /* small vectors (SM_*); from quantisation on: cdw[MAXN/2] | residual / LSB bits (160 words) */
     int   pc[LC3D_PLAN_HEAD_WORDS];  /* the scalar head of the plan (lc3d_plan up to pad0), copied once: stage code reads it from LDS
                                    instead of through a flat pointer, and readfirstlane makes the values scalar */
     int   cc[14];               /* this channel-stream's lc3d_chan */
@@ -74,7 +89,7 @@ struct __attribute__((aligned(16))) WaveLds {
 #endif
 };
 static_assert(offsetof(lc3d_plan, tw1) == 4 * LC3D_PLAN_HEAD_WORDS, "plan head size");
-static_assert(offsetof(WaveLds, A) % 16 == 0 && (offsetof(WaveLds, sm) + 242 * 4) % 16 == 0 && offsetof(WaveLds, xbuf) == 0, "16-byte aligned LDS rows");
+static_assert(offsetof(WaveLds, A) % 16 == 0 && (offsetof(WaveLds, sm) + (MAXN / 2 + 2) * 4) % 16 == 0 && offsetof(WaveLds, xbuf) == 0, "16-byte aligned LDS rows");
 #define PI(f) uni(L.pc[offsetof(lc3d_plan, f) / 4])
 #define PF(f) __int_as_float(uni(L.pc[offsetof(lc3d_plan, f) / 4]))
 #define CI(f) uni(L.cc[offsetof(lc3d_chan, f) / 4])
@@ -83,7 +98,7 @@ static_assert(offsetof(WaveLds, A) % 16 == 0 && (offsetof(WaveLds, sm) + 242 * 4
 #define SPEC(L) ((L).A)
 #define BYTES(L) ((uint8_t*)(L).A)            /* up to 640 bytes, valid from the bitstream stage to the copy-out */
 #define CDW(L)  ((uint32_t*)&(L).sm[0])      /* per 2-tuple: ctx(10) | maxlev+1 (6) | pki of the final symbol (6) | sym (5) */
-#define RESB(L) ((uint8_t*)&(L).sm[240])     /* 640 bytes: residual bits / LSB-mode list (bit-packed, LSB first) */
+#define RESB(L) ((uint8_t*)&(L).sm[MAXN / 2]) /* 640 bytes: residual bits / LSB-mode list (bit-packed, LSB first) */
 
 /* sm[] map (floats) before quantisation */
 #define SM_ENER   0     /* 64  band energies, later the interpolated SNS gains */
@@ -853,6 +868,48 @@ STAGE void mdct_dft160_stage1(const lc3d_plan* __restrict__ P, WaveLds& L, int l
     }
     LSYNC();
 }
+#ifdef LC3_BIG
+/* 480 = 15 x 32 Good-Thomas (R/fft/fft_240_480.h:90-185): index tables table1[k + 15 l] = (256 k + 225 l) mod 480 for the fifteen
+ * 32-point column transforms (two lanes each, in place), the same table as (225 k + 256 l) mod 480 for the thirty-two 15-point row
+ * transforms, output table2[15 k + l] = (15 k + 32 l) mod 480.  X -> A. */
+STAGE void mdct_dft480_cols(WaveLds& L, int lane)
+{
+    float* X = XCUR(L);
+    const bool on = lane < 30;
+    const int k = on ? lane >> 1 : 0, half = lane & 1;
+    float sd[32], o[32];
+#pragma unroll
+    for (int l = 0; l < 16; l++) {
+        const int sa = (256 * k + 225 * l) % 480, sb = (256 * k + 225 * (l + 16)) % 480;
+        const float ar = X[2 * sa], ai = X[2 * sa + 1], br = X[2 * sb], bi = X[2 * sb + 1];
+        sd[2 * l] = half ? ar - br : ar + br; sd[2 * l + 1] = half ? ai - bi : ai + bi;
+    }
+    if (half) dft32_half<true>(sd, o); else dft32_half<false>(sd, o);
+    LSYNC();
+    if (on) {
+#pragma unroll
+        for (int m = 0; m < 16; m++) {
+            const int bin = half ? (m < 8 ? 2 * m + 1 : 2 * (m - 8) + 17) : 2 * m;
+            const int d = (256 * k + 225 * bin) % 480;
+            X[2 * d] = o[2 * m]; X[2 * d + 1] = o[2 * m + 1];
+        }
+    }
+    LSYNC();
+}
+STAGE void mdct_dft480_rows(WaveLds& L, int lane)
+{
+    const float* X = XCUR(L);
+    if (lane < 32) {
+        float v[30];
+#pragma unroll
+        for (int l = 0; l < 15; l++) { const int s = (225 * lane + 256 * l) % 480; v[2 * l] = X[2 * s]; v[2 * l + 1] = X[2 * s + 1]; }
+        dft15(v);
+#pragma unroll
+        for (int l = 0; l < 15; l++) { const int d = (15 * lane + 32 * l) % 480; L.A[2 * d] = v[2 * l]; L.A[2 * d + 1] = v[2 * l + 1]; }
+    }
+    LSYNC();
+}
+#endif
 template <int RAD> __device__ __forceinline__ void pfa_stage_r(const uint8_t* __restrict__ map, const uint8_t* __restrict__ dst, const float* in, float* out, int cnt, int lane)
 {
     float v[2 * RAD];
@@ -970,9 +1027,10 @@ STAGE void mdct_post(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
 {
     const int N = PI(N), h = N >> 1;
     const float norm = PF(dct4_norm);
-    float o0[4], o1[4];                              /* post-twiddle R/dct4.c:90-94, in place in A through registers (h <= 256) */
+    constexpr int NK = (MAXN / 2 + WAVE - 1) / WAVE;
+    float o0[NK], o1[NK];                            /* post-twiddle R/dct4.c:90-94, in place in A through registers */
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < NK; k++) {
         const int i = lane + 64 * k;
         if (i < h) {
             const float ar = L.A[2 * i], ai = L.A[2 * i + 1], br = P->tw2[2 * i], bi = P->tw2[2 * i + 1];
@@ -982,7 +1040,7 @@ STAGE void mdct_post(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
     }
     LSYNC();
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < NK; k++) {
         const int i = lane + 64 * k;
         if (i < h) { L.A[2 * i] = o0[k]; L.A[N - 2 * i - 1] = o1[k]; }
     }
@@ -1672,11 +1730,16 @@ __device__ __forceinline__ int opaque_i(int v) { asm volatile("" : "+v"(v)); ret
 
 /* number of leading (low-j) energies a probe has to visit: while even the smallest candidate of the wave sees
  * en[j] - cand < thr7 and no lane has left the all-zero state, a step is a no-op, so the trailing run of such j is skipped */
-__device__ __forceinline__ int gain_probe_len(float thr7, float e0, float e1, int lane, int nq, int cand_min)
+__device__ __forceinline__ int gain_probe_len(float thr7, const float* ev /* [NQL]: energies of j = lane + 64 h */, int lane, int nq, int cand_min)
 {
     const float fmin = (float)cand_min;
-    const unsigned long long m0 = __ballot(lane < nq && !(e0 - fmin < thr7)), m1 = __ballot(lane + 64 < nq && !(e1 - fmin < thr7));
-    return uni(m1 ? 128 - (int)__clzll((long long)m1) : m0 ? 64 - (int)__clzll((long long)m0) : 0);
+    int len = 0;
+#pragma unroll
+    for (int h = 0; h < NQL; h++) {
+        const unsigned long long m = __ballot(lane + 64 * h < nq && !(ev[h] - fmin < thr7));
+        if (m) len = 64 * (h + 1) - (int)__clzll((long long)m);
+    }
+    return uni(len);
 }
 
 __device__ __forceinline__ bool gain_probe(float thr7, float thr50, const float* en, int nq, int cand, float target)
@@ -1740,10 +1803,11 @@ STAGE void st_gain_estimate(const lc3d_plan* __restrict__ P, const lc3d_chan* __
         ind_min = (float)ceil(28.0 * (double)m_log10f(g_min));
         float* en = XCUR(L);                         /* X is scratch between TNS and quantisation */
         SUB(10);
-        float ev[2] = {0, 0};
+        float ev[NQL];
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
+        for (int h = 0; h < NQL; h++) {
             const int j = lane + 64 * h;
+            ev[h] = 0;
             if (j < nq) {
                 const float* x = &L.A[4 * j];
                 float t = x[0] * x[0];
@@ -1761,14 +1825,14 @@ STAGE void st_gain_estimate(const lc3d_plan* __restrict__ P, const lc3d_chan* __
         {
             const int lvl = lane ? ilog2((unsigned)lane) : 0, p = lane - (1 << lvl);
             const int cand = offset0 - (p << (8 - lvl)) - (128 >> lvl);
-            const unsigned long long addback = __ballot(gain_probe(thr7, thr50, en, gain_probe_len(thr7, ev[0], ev[1], lane, nq, offset0 - 252), cand, target));
+            const unsigned long long addback = __ballot(gain_probe(thr7, thr50, en, gain_probe_len(thr7, ev, lane, nq, offset0 - 252), cand, target));
             int node = 1;
             for (int i = 0; i < 6; i++) { const int nb = ((addback >> node) & 1ull) ? 0 : 1; m += nb << (7 - i); node = 2 * node + nb; }
         }
         SUB(12);
         {   /* last two steps: lane 0: step 6; lane 1: step 7 if step 6 added back; lane 2: step 7 otherwise */
             const int cand = lane == 0 ? offset0 - m - 2 : lane == 1 ? offset0 - m - 1 : offset0 - m - 3;
-            const unsigned long long addback = __ballot(gain_probe(thr7, thr50, en, gain_probe_len(thr7, ev[0], ev[1], lane, nq, offset0 - m - 3), cand, target));
+            const unsigned long long addback = __ballot(gain_probe(thr7, thr50, en, gain_probe_len(thr7, ev, lane, nq, offset0 - m - 3), cand, target));
             if (addback & 1ull) { if (!(addback & 2ull)) m += 1; }
             else { m += 2; if (!(addback & 4ull)) m += 1; }
         }
@@ -1952,7 +2016,7 @@ STAGE void st_noise_factor(const lc3d_plan* __restrict__ P, WaveLds& L, int lane
     if (!split) {
         /* common case: one serial sum over all zero lines.  They are compacted (in bin order) into LDS scratch three chunks
          * at a time and summed with uniform-address reads. */
-        float* lst = &L.sm[242];                    /* 306 free words (16-byte aligned): the residual-bit area is not in use yet */
+        float* lst = &L.sm[MAXN / 2 + 2];           /* >= 306 free words (16-byte aligned): the residual-bit area is not in use yet */
         j1 = nz;
 #pragma unroll
         for (int g = 0; g < 8; g += 3) {
@@ -2368,8 +2432,8 @@ STAGE void st_bitstream(const lc3d_plan* __restrict__ P, const lc3d_chan* __rest
 /* ------------------------------------------------------------------------------------------------ */
 /* the kernel: one wave per channel-stream, frames in time order  (frame driver R/enc_lc3_fl.c:13-160) */
 /* ------------------------------------------------------------------------------------------------ */
-extern "C" __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(4, 4)))
-lc3_encode_kernel(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans, float* __restrict__ state,
+extern "C" __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(KERNEL_WAVES, KERNEL_WAVES)))
+KERNEL_NAME(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans, float* __restrict__ state,
                   const void* __restrict__ pcm, int bitdepth, int T, uint8_t* __restrict__ out, int out_stride, int ncs,
                   lc3d_trace* __restrict__ trace)
 {
@@ -2385,12 +2449,12 @@ lc3_encode_kernel(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__
     const int strm = cs / channels, ch = cs - strm * channels;
 
     /* ---- load cross-frame state ---- */
-    float* stp = state + (size_t)cs * LC3D_STATE_WORDS;
+    float* stp = state + (size_t)cs * LC3D_STATE_WORDS(MEMCAP);
     for (int i = lane; i < MEMCAP; i += WAVE) L.xbuf[i] = stp[LC3D_ST_XPREV + i];
-    for (int i = lane; i < 384; i += WAVE) L.h12[i] = stp[LC3D_ST_H12 + i];
-    for (int i = lane; i < 194; i += WAVE) L.h6[i] = stp[LC3D_ST_H6 + i];
-    if (lane < 12) L.fsc[lane] = stp[LC3D_ST_SCAL + lane];
-    if (lane < 16) L.isc[lane] = ((const int*)stp)[LC3D_ST_SCAL + 16 + lane];
+    for (int i = lane; i < 384; i += WAVE) L.h12[i] = stp[LC3D_ST_H12(MEMCAP) + i];
+    for (int i = lane; i < 194; i += WAVE) L.h6[i] = stp[LC3D_ST_H6(MEMCAP) + i];
+    if (lane < 12) L.fsc[lane] = stp[LC3D_ST_SCAL(MEMCAP) + lane];
+    if (lane < 16) L.isc[lane] = ((const int*)stp)[LC3D_ST_SCAL(MEMCAP) + 16 + lane];
     LSYNC();
     if (CI(reset_attack) && lane == 0) { L.fsc[F_ATT_M0] = 0; L.fsc[F_ATT_M1] = 0; L.fsc[F_ATT_ACC] = 0; L.isc[I_ATT_POS] = 0; L.isc[I_ATT_FLAG] = 0; }
     LSYNC();
@@ -2438,6 +2502,9 @@ lc3_encode_kernel(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__
         if (CI(attack_handling)) st_attack(P, L, lane);
         TICK(5);
         mdct_pre(P, L, lane);
+#ifdef LC3_BIG
+        if (PI(N) == 960) { mdct_dft480_cols(L, lane); mdct_dft480_rows(L, lane); } else
+#endif
         if (PI(N) == 480) { mdct_dft240_cols(L, lane); mdct_dft240_rows(L, lane); }
         else if (PI(N) == 120) mdct_dft60(P, L, lane);
         else { if (PI(N) == 320) mdct_dft160_stage1(P, L, lane); else if (PI(N) == 160) mdct_dft80_stage1(P, L, lane); mdct_dft_pfa(P, L, lane); }
@@ -2521,18 +2588,22 @@ lc3_encode_kernel(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__
 #endif
     /* ---- store cross-frame state ---- */
     for (int i = lane; i < MEMCAP; i += WAVE) stp[LC3D_ST_XPREV + i] = L.xbuf[i];
-    for (int i = lane; i < 384; i += WAVE) stp[LC3D_ST_H12 + i] = L.h12[i];
-    for (int i = lane; i < 194; i += WAVE) stp[LC3D_ST_H6 + i] = L.h6[i];
-    if (lane < 12) stp[LC3D_ST_SCAL + lane] = L.fsc[lane];
-    if (lane < 16) ((int*)stp)[LC3D_ST_SCAL + 16 + lane] = L.isc[lane];
+    for (int i = lane; i < 384; i += WAVE) stp[LC3D_ST_H12(MEMCAP) + i] = L.h12[i];
+    for (int i = lane; i < 194; i += WAVE) stp[LC3D_ST_H6(MEMCAP) + i] = L.h6[i];
+    if (lane < 12) stp[LC3D_ST_SCAL(MEMCAP) + lane] = L.fsc[lane];
+    if (lane < 16) ((int*)stp)[LC3D_ST_SCAL(MEMCAP) + 16 + lane] = L.isc[lane];
     (void)ml;
 }
 
 /* ------------------------------------------------------------------------------------------------ */
 /* C-ABI device shim (lc3_shim.h): context, uploads, launch                                          */
 /* ------------------------------------------------------------------------------------------------ */
+#ifndef LC3_BIG                 /* the large-layout object holds only its kernel */
+extern "C" __global__ void lc3_encode_kernel_big(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans, float* __restrict__ state,
+                                                 const void* __restrict__ pcm, int bitdepth, int T, uint8_t* __restrict__ out, int out_stride, int ncs,
+                                                 lc3d_trace* __restrict__ trace);
 struct lc3hip_ctx {
-    int device, ncs, n_streams, channels, N;
+    int device, ncs, n_streams, channels, N, big, state_words;
     lc3d_plan* d_plan; lc3d_chan* d_chans; float* d_state;
     void* d_pcm; size_t pcm_cap; uint8_t* d_out; size_t out_cap;
     lc3d_trace* d_trace; size_t trace_cap;
@@ -2551,10 +2622,12 @@ extern "C" int lc3hip_create(void** out_ctx, const lc3d_plan* plan, int n_stream
     c->device = device;
     HIPCHK(hipSetDevice(device));
     c->n_streams = n_streams; c->channels = plan->channels; c->ncs = n_streams * plan->channels; c->N = plan->N;
+    c->big = LC3D_LAYOUT_BIG(plan->N, plan->la);
+    c->state_words = LC3D_STATE_WORDS(c->big ? LC3D_MEMCAP_BIG : LC3D_MEMCAP_STD);
     HIPCHK(hipMalloc((void**)&c->d_plan, sizeof(lc3d_plan)));
     HIPCHK(hipMemcpy(c->d_plan, plan, sizeof(lc3d_plan), hipMemcpyHostToDevice));
     HIPCHK(hipMalloc((void**)&c->d_chans, sizeof(lc3d_chan) * c->ncs));
-    HIPCHK(hipMalloc((void**)&c->d_state, sizeof(float) * LC3D_STATE_WORDS * (size_t)c->ncs));
+    HIPCHK(hipMalloc((void**)&c->d_state, sizeof(float) * c->state_words * (size_t)c->ncs));
     HIPCHK(hipStreamCreate(&c->stream));
     HIPCHK(hipEventCreate(&c->ev0)); HIPCHK(hipEventCreate(&c->ev1));
     *out_ctx = c;
@@ -2565,10 +2638,11 @@ extern "C" int lc3hip_reset_state(void* ctx, const float* init_state_one /* LC3D
 {
     lc3hip_ctx* c = (lc3hip_ctx*)ctx;
     HIPCHK(hipSetDevice(c->device));
-    float* h = (float*)malloc(sizeof(float) * LC3D_STATE_WORDS * (size_t)c->ncs);
+    const size_t sw = (size_t)c->state_words;
+    float* h = (float*)malloc(sizeof(float) * sw * (size_t)c->ncs);
     if (!h) return 1;
-    for (int i = 0; i < c->ncs; i++) memcpy(h + (size_t)i * LC3D_STATE_WORDS, init_state_one, sizeof(float) * LC3D_STATE_WORDS);
-    hipError_t e = hipMemcpy(c->d_state, h, sizeof(float) * LC3D_STATE_WORDS * (size_t)c->ncs, hipMemcpyHostToDevice);
+    for (int i = 0; i < c->ncs; i++) memcpy(h + (size_t)i * sw, init_state_one, sizeof(float) * sw);
+    hipError_t e = hipMemcpy(c->d_state, h, sizeof(float) * sw * (size_t)c->ncs, hipMemcpyHostToDevice);
     free(h);
     HIPCHK(e);
     return 0;
@@ -2610,8 +2684,10 @@ extern "C" int lc3hip_encode(void* ctx, const void* pcm, int pcm_on_device, int 
         dtr = c->d_trace;
     }
     HIPCHK(hipEventRecord(c->ev0, s));
-    hipLaunchKernelGGL(lc3_encode_kernel, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames,
-                       dout, out_stride, c->ncs, dtr);
+    if (c->big) hipLaunchKernelGGL(lc3_encode_kernel_big, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames,
+                                   dout, out_stride, c->ncs, dtr);
+    else hipLaunchKernelGGL(lc3_encode_kernel, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames,
+                            dout, out_stride, c->ncs, dtr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev1, s));
     if (!out_on_device) HIPCHK(hipMemcpyAsync(out, dout, out_bytes, hipMemcpyDeviceToHost, s));
@@ -2648,3 +2724,4 @@ extern "C" int lc3hip_destroy(void* ctx)
     free(c);
     return 0;
 }
+#endif /* !LC3_BIG */

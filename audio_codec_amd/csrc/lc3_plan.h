@@ -12,7 +12,7 @@
 #define LC3_PLAN_H
 #include <stdint.h>
 
-#define LC3D_MAX_N 480          /* largest frame length built so far (48 kHz / 10 ms, 96 kHz / 2.5-5 ms) */
+#define LC3D_MAX_N 960          /* largest frame length (96 kHz / 10 ms); the kernels come in two LDS layouts, see lc3_kernels.hip */
 #define LC3D_PFA_STRIDE 160     /* longest prime-factor DFT (32 kHz / 10 ms: 160 = 32 x 5) */
 #define LC3D_GAIN_TAB 512       /* gain index k = ind + gg_off in [-256, 255] -> tab[k + 256] */
 
@@ -54,14 +54,18 @@ typedef struct {
     int32_t pad[3];
 } lc3d_chan;
 
-/* ---- state layout (32-bit words) ---- */
-#define LC3D_ST_XPREV   0                         /* MDCT / resampler memory: tail of the previous frame, right-aligned in 300 words */
-#define LC3D_ST_H12     (LC3D_ST_XPREV + 300)   /* last 384 samples of the HP-filtered 12.8 kHz stream */
-#define LC3D_H12_KEEP   384
-#define LC3D_ST_H6      (LC3D_ST_H12 + LC3D_H12_KEEP)  /* last 194 samples of the 6.4 kHz stream */
-#define LC3D_H6_KEEP    194
-#define LC3D_ST_SCAL    (LC3D_ST_H6 + LC3D_H6_KEEP + 2)   /* 16 float scalars (kernel fsc[0..15]) then 16 int scalars (isc[0..15]) */
-#define LC3D_S_OLPA_PITCH_WORD (LC3D_ST_SCAL + 16 + 0) /* isc[I_OLPA_PITCH]: initial value 17 (R/setup_enc_lc3.c:178) */
-#define LC3D_STATE_WORDS 960
+/* ---- state layout (32-bit words), parametrised by the kernel layout's MDCT-memory slot (300 standard, 600 large) ---- */
+#define LC3D_MEMCAP_STD 300
+#define LC3D_MEMCAP_BIG 600                       /* 96 kHz / 10 ms: N - la_zeros = 960 - 360 */
+#define LC3D_LAYOUT_BIG(N, la) ((N) > 480 || (N) - (la) > LC3D_MEMCAP_STD)
+#define LC3D_ST_XPREV   0                         /* MDCT / resampler memory: tail of the previous frame, right-aligned in the slot */
+#define LC3D_H12_KEEP   384                       /* last 384 samples of the HP-filtered 12.8 kHz stream */
+#define LC3D_H6_KEEP    194                       /* last 194 samples of the 6.4 kHz stream */
+#define LC3D_ST_H12(mc)  (LC3D_ST_XPREV + (mc))
+#define LC3D_ST_H6(mc)   (LC3D_ST_H12(mc) + LC3D_H12_KEEP)
+#define LC3D_ST_SCAL(mc) (LC3D_ST_H6(mc) + LC3D_H6_KEEP + 2)   /* 16 float scalars (kernel fsc[0..15]) then 16 int scalars (isc[0..15]) */
+#define LC3D_S_OLPA_PITCH_WORD(mc) (LC3D_ST_SCAL(mc) + 16 + 0) /* isc[I_OLPA_PITCH]: initial value 17 (R/setup_enc_lc3.c:178) */
+#define LC3D_STATE_WORDS(mc) ((mc) + 660)
+#define LC3D_STATE_WORDS_MAX LC3D_STATE_WORDS(LC3D_MEMCAP_BIG)
 
 #endif

@@ -115,7 +115,7 @@ static void frame_params(lc3o_enc* e)
         e->tw2[i] = cexpi_f(-M_PI * i / len);
     }
     e->dct4_norm = 1.0 / sqrtf(len / 2);                       /* R/dct4.c:82 */
-    { const int h = len / 2; e->fft_kind = (h == 10 || h == 20 || h == 30 || h == 40 || h == 60 || h == 80 || h == 120 || h == 160 || h == 240) ? h : 0; }
+    { const int h = len / 2; e->fft_kind = (h == 10 || h == 20 || h == 30 || h == 40 || h == 60 || h == 80 || h == 120 || h == 160 || h == 240 || h == 480) ? h : 0; }
     /* DCT-II(16) post-twiddle: R/dct4.c:43-45 */
     for (int i = 0; i < 16; i++) {
         cpx s = {2 / sqrtf(2 * 16), 0};

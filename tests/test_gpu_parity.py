@@ -74,6 +74,9 @@ def test_golden_stereo():
     (48000, 2.5, 0, 120, [64000, 96000, 128000, 320000] * 2),
     (44100, 5.0, 0, 240, [64000, 128000] * 2),
     (48000, 2.5, 1, 120, [172800, 256000, 400000] * 2),
+    # the large-layout kernel: N = 960, or an MDCT memory of 360 samples
+    (96000, 5.0, 1, 480, [256000, 400000, 600000] * 2),
+    (96000, 10.0, 1, 960, [149600, 256000, 400000, 500000] * 2),
 ])
 def test_vs_oracle_same_math(fs, ms, hr, N, rates):
     B, T = len(rates), 24

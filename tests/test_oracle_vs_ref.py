@@ -70,6 +70,7 @@ def test_api_error_codes_match():
     (48000, 5.0, 0, 240, [32000, 64000, 96000, 128000, 256000]),
     (24000, 10.0, 0, 240, [16000, 32000, 64000, 128000]),
     (96000, 5.0, 1, 480, [256000, 400000]),
+    (96000, 10.0, 1, 960, [149600, 256000, 500000]),
     (48000, 10.0, 1, 480, [128000, 256000, 400000]),
     (48000, 5.0, 1, 240, [160000, 320000]),
     (44100, 10.0, 0, 480, [32000, 64000, 128000]),
@@ -95,7 +96,7 @@ def test_other_geometries(fs, ms, hr, N, rates):
         assert (r == o).all()
 
 
-@pytest.mark.parametrize("n", [2, 3, 4, 5, 8, 15, 16, 32, 10, 20, 30, 40, 60, 80, 120, 160, 240])
+@pytest.mark.parametrize("n", [2, 3, 4, 5, 8, 15, 16, 32, 10, 20, 30, 40, 60, 80, 120, 160, 240, 480])
 def test_dft_kernels_match_the_reference_fft(n):
     """The restated DFT kernels (oracle/lc3_oracle_fft.inc) against LC3_iisfft_apply of the compiled reference, bit for bit."""
     import ctypes as C
