@@ -103,6 +103,6 @@ def test_batch_argument_validation(lib):
     assert f(C.byref(h), 2, 48000, 3, 10.0, 0, br, -1) == 5
     assert f(C.byref(h), 2, 48000, 1, 7.5, 0, br, -1) == 9
     assert f(C.byref(h), 2, 32000, 1, 10.0, 1, br, -1) == 4
-    assert f(C.byref(h), 2, 96000, 1, 10.0, 0, br, -1) == 1      # 96 kHz forces hrmode (R/setup_enc_lc3.c:93-96); N = 960 is not built yet
+    assert f(C.byref(h), 2, 96000, 1, 10.0, 0, br, -1) == 6      # 96 kHz forces hrmode (R/setup_enc_lc3.c:93-96); 64 kbps is below the hrmode minimum
     bad = (C.c_int * 2)(64000, 1000)
     assert f(C.byref(h), 2, 48000, 1, 10.0, 0, bad, -1) in (1, 6)   # bitrate error (6) unless no device was found first (1)
