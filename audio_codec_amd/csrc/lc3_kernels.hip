@@ -583,7 +583,9 @@ STAGE void st_ltpf(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict_
         }
         LSYNC();
         int tsel;
-        { float v = lane < 16 && lane < t_max - t_min - 8 + 1 ? cor[4 + lane] : -INFINITY; int vi = lane & 15; wave_argmax_first<16>(v, vi);
+        /* searchMaxIndice of R/ltpf_coder.c:15-32 starts from max = 0 and takes strictly greater values: a NaN correlation (the
+         * running energy can round below zero on an all-zero history) is never taken - here it is mapped to -inf first */
+        { float v = lane < 16 && lane < t_max - t_min - 8 + 1 ? cor[4 + lane] : -INFINITY; v = v == v ? v : -INFINITY; int vi = lane & 15; wave_argmax_first<16>(v, vi);
           tsel = unif(v) > 0 ? uni(vi) : 0; }
         const int t1 = tsel + t0_min;
         int pitch_int, pitch_fr;
@@ -604,7 +606,7 @@ STAGE void st_ltpf(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict_
             const int mid = 4 * (t1 - t0_min) + 1, up = 4 - step, down = t1 == t0_min ? 0 : 4 - step;
             const int cnt = ((mid + up) - (mid - down)) / step + 1;
             int ksel;
-            { float v = (lane & 15) < cnt ? cor_int[mid - down - 1 + (lane & 15) * step] : -INFINITY; int vi = lane & 15; wave_argmax_first<16>(v, vi);
+            { float v = (lane & 15) < cnt ? cor_int[mid - down - 1 + (lane & 15) * step] : -INFINITY; v = v == v ? v : -INFINITY; int vi = lane & 15; wave_argmax_first<16>(v, vi);
               ksel = unif(v) > 0 ? uni(vi) : 0; }
             pitch_fr = ksel * step - down;
             if (pitch_fr >= 0) pitch_int = t1; else { pitch_int = t1 - 1; pitch_fr = 4 + pitch_fr; }

@@ -30,7 +30,7 @@ def main():
     streams = [int(x) for x in args[6].split(",")] if len(args) > 6 else list(range(B))
     B = len(streams)
     N = int(fs * ms / 1000)
-    pcm = synth_pcm(max(streams) + 1, T, N, fs, seed=11)[streams]
+    pcm = synth_pcm(max(streams) + 1, T, N, fs, seed=int(os.environ.get("DBG_SEED", "11")))[streams]
     rates = [br] * B
     bt = audio_codec_amd.Batch(B, fs, 1, ms, hr, rates, device=0)
     got, traces = bt.encode_traced(pcm)

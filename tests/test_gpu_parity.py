@@ -267,3 +267,14 @@ def test_large_sweep_vs_oracle(fs, ms, hr, N, B, T, rates):
     nb = np.array([b.num_bytes(i) for i in range(B)])
     bad = [(i, t) for i in range(B) for t in range(T) if (got[i, t, :nb[i]] != want[i, t, :nb[i]]).any()]
     assert not bad, (len(bad), bad[:8])
+
+
+def test_soak_every_operating_point():
+    """All 24 (sample rate, frame length, mode) families of the reference x 2 seeds x 32 streams x 36 frames against the oracle
+    (tools/soak.py; the full-size run, 1.5 M frames, is quoted in DESIGN.md)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("soak", os.path.join(root, "tools", "soak.py"))
+    soak = importlib.util.module_from_spec(spec); spec.loader.exec_module(soak)
+    tot, bad = soak.run(2, 32, 36, verbose=False)
+    assert tot == 24 * 2 * 32 * 36 and bad == 0, (tot, bad)

@@ -1,0 +1,52 @@
+"""Differential soak (GPU box): every operating point x several seeds, GPU frames against the oracle's batch entry (same math).
+Usage: python tools/soak.py [seeds] [streams] [frames]   -> prints one line per configuration and a total; exit code 1 on any difference."""
+import ctypes as C, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import audio_codec_amd
+from lc3_harness import synth_pcm, ORACLE_DIR
+
+L = C.CDLL(os.path.join(ORACLE_DIR, "liblc3_oracle_pm.so"))
+L.lc3o_encode_batch16.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+def configurations():
+    cfg = []
+    for fs in (8000, 16000, 24000, 32000, 44100, 48000):
+        for ms in (10.0, 5.0, 2.5):
+            lo = {10.0: 16000 if fs != 44100 else 32000, 5.0: 32000, 2.5: 64000}[ms]
+            cfg.append((fs, ms, 0, [lo, 2 * lo, 3 * lo, 4 * lo, 6 * lo, 320000 if fs != 44100 else 256000]))
+    for ms, lo in ((10.0, 124800), (5.0, 148800), (2.5, 172800)):
+        cfg.append((48000, ms, 1, [lo, 256000, 400000, 500000]))
+    for ms, lo in ((10.0, 149600), (5.0, 174400), (2.5, 198400)):
+        cfg.append((96000, ms, 1, [lo, 256000, 400000, 500000]))
+    return cfg
+
+
+def run(NS, B, T, verbose=True):
+    """returns (frames compared, frames that differ)"""
+    tot = bad = 0
+    for fs, ms, hr, rates in configurations():
+        N = int(round((48000 if fs == 44100 else fs) * ms / 1000))
+        for seed in range(NS):
+            br = np.array([rates[(i + seed) % len(rates)] for i in range(B)], np.int32)
+            pcm = synth_pcm(B, T, N, fs, seed=4000 + 17 * seed)
+            b = audio_codec_amd.Batch(B, fs, 1, ms, hr, list(map(int, br)), device=0)
+            got = np.concatenate([b.encode(pcm[:, :T // 3]), b.encode(pcm[:, T // 3:])], axis=1)
+            want = np.zeros_like(got)
+            rc = L.lc3o_encode_batch16(fs, ms, hr, B, T, br.ctypes.data, np.ascontiguousarray(pcm).ctypes.data, want.ctypes.data, b.stride)
+            assert rc == 0, rc
+            nb = np.array([b.num_bytes(i) for i in range(B)])
+            d = sum(int((got[i, :, :nb[i]] != want[i, :, :nb[i]]).any(axis=1).sum()) for i in range(B))
+            tot += B * T; bad += d
+            if d and verbose: print("%6d Hz %4.1f ms hr%d seed %d: %d of %d frames differ" % (fs, ms, hr, seed, d, B * T))
+    return tot, bad
+
+
+if __name__ == "__main__":
+    NS = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+    T = int(sys.argv[3]) if len(sys.argv) > 3 else 48
+    t0 = time.time()
+    tot, bad = run(NS, B, T)
+    print("soak: %d frames over %d configurations x %d seeds, %d differ, %.0f s" % (tot, len(configurations()), NS, bad, time.time() - t0))
+    sys.exit(1 if bad else 0)
