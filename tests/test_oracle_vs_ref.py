@@ -113,3 +113,23 @@ def test_dft_kernels_match_the_reference_fft(n):
         ref.LC3_iisfft_apply(h, a.ctypes.data)
         assert orc.lc3o_dft(b.ctypes.data, n) == 1
         assert (a.view(np.uint32) == b.view(np.uint32)).all()
+
+
+def test_soak_every_operating_point_against_the_reference():
+    """The 24 (sample rate, frame length, mode) families x mixed bitrates x 12 streams x 40 frames: restatement == compiled reference,
+    byte for byte (same configuration list as the GPU soak, tools/soak.py)."""
+    cfg = []
+    for fs in (8000, 16000, 24000, 32000, 44100, 48000):
+        for ms in (10.0, 5.0, 2.5):
+            lo = {10.0: 16000 if fs != 44100 else 32000, 5.0: 32000, 2.5: 64000}[ms]
+            cfg.append((fs, ms, 0, [lo, 2 * lo, 3 * lo, 4 * lo, 6 * lo, 320000 if fs != 44100 else 256000]))
+    for ms, lo in ((10.0, 124800), (5.0, 148800), (2.5, 172800)):
+        cfg.append((48000, ms, 1, [lo, 256000, 400000, 500000]))
+    for ms, lo in ((10.0, 149600), (5.0, 174400), (2.5, 198400)):
+        cfg.append((96000, ms, 1, [lo, 256000, 400000, 500000]))
+    for fs, ms, hr, rates in cfg:
+        N = int(round((48000 if fs == 44100 else fs) * ms / 1000))
+        br = [rates[i % len(rates)] for i in range(12)]
+        pcm = synth_pcm(64, 40, N, fs, seed=4000)[[0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 62, 63]]     # 62 / 63: the silent and the full-scale stream
+        for r, o in zip(ref_encode_streams(pcm, fs, ms, hr, br), oracle_encode_streams(pcm, fs, ms, hr, br)):
+            assert (r == o).all(), (fs, ms, hr)
