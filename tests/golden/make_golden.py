@@ -45,3 +45,26 @@ allpcm = x[:Tall * 480].reshape(1, Tall, 480)
 full = ref_encode_streams(allpcm, 48000, 10.0, 0, [64000])[0]
 save("c0_thetest48_64k_first64", fs=48000, frame_ms=10.0, hrmode=0, pcm=allpcm[:, :64].copy(), frames=full[None, :64].copy(),
      full_frames=Tall, full_pcm_md5=hashlib.md5(allpcm.tobytes()).hexdigest(), full_bitstream_md5=hashlib.md5(full.tobytes()).hexdigest())
+
+# the other operating points (one small fixture per sample rate / frame length family outside 48 kHz / 10 ms)
+def family(name, cfgs, T=12):
+    out = {}
+    for tag, fs, ms, hr, N, rates in cfgs:
+        pcm = synth_pcm(3, T, N, 48000 if fs == 44100 else fs)[[0, 1, 2][:len(rates)]]
+        outs = ref_encode_streams(pcm, fs, ms, hr, rates)
+        stride = max(o.shape[1] for o in outs)
+        fr = np.zeros((len(rates), T, stride), np.uint8)
+        for b, o in enumerate(outs): fr[b, :, :o.shape[1]] = o
+        out[tag + "_cfg"] = np.array([fs, int(ms * 10), hr, N]); out[tag + "_rates"] = np.array(rates); out[tag + "_pcm"] = pcm
+        out[tag + "_frames"] = fr; out[tag + "_nbytes"] = np.array([o.shape[1] for o in outs])
+    save(name, tags=np.array([c[0] for c in cfgs]), **out)
+
+family("c6_other_operating_points", [
+    ("nb8k_10", 8000, 10.0, 0, 80, [16000, 32000]), ("nb8k_2p5", 8000, 2.5, 0, 20, [64000, 96000]),
+    ("wb16k_10", 16000, 10.0, 0, 160, [32000, 64000]), ("wb16k_5", 16000, 5.0, 0, 80, [32000, 64000]),
+    ("sswb24k_5", 24000, 5.0, 0, 120, [32000, 96000]), ("sswb24k_2p5", 24000, 2.5, 0, 60, [64000, 96000]),
+    ("swb32k_10", 32000, 10.0, 0, 320, [64000, 128000]), ("swb32k_2p5", 32000, 2.5, 0, 80, [64000, 128000]),
+    ("fb44k_10", 44100, 10.0, 0, 480, [64000, 128000]), ("fb48k_2p5", 48000, 2.5, 0, 120, [64000, 128000]),
+    ("hr48k_5", 48000, 5.0, 1, 240, [160000, 320000]), ("hr96k_5", 96000, 5.0, 1, 480, [256000, 400000]),
+    ("hr96k_10", 96000, 10.0, 1, 960, [149600, 400000]),
+])

@@ -278,3 +278,29 @@ def test_soak_every_operating_point():
     soak = importlib.util.module_from_spec(spec); spec.loader.exec_module(soak)
     tot, bad = soak.run(2, 32, 36, verbose=False)
     assert tot == 24 * 2 * 32 * 36 and bad == 0, (tot, bad)
+
+
+def test_golden_other_operating_points():
+    """the reference's own vectors (tests/golden/c6, generated by make_golden.py) for every family outside 48 kHz / 10 ms"""
+    g = np.load(os.path.join(G, "c6_other_operating_points.npz"))
+    tot = same = 0
+    for tag in g["tags"]:
+        tag = str(tag)
+        fs, dms, hr, N = (int(v) for v in g[tag + "_cfg"])
+        rates, pcm, frames, nbytes = g[tag + "_rates"], g[tag + "_pcm"], g[tag + "_frames"], g[tag + "_nbytes"]
+        b = _amd().Batch(len(rates), fs, 1, dms / 10.0, hr, [int(r) for r in rates], device=0)
+        got = b.encode(pcm)
+        s, t = _frames_equal(got, [frames[i][:, :nbytes[i]] for i in range(len(rates))])
+        tot += t; same += s
+    assert same >= 0.99 * tot, (same, tot)
+
+
+@pytest.mark.parametrize("fs,ms,hr,br", [(16000, 10.0, 0, 32000), (8000, 2.5, 0, 64000), (32000, 10.0, 0, 64000), (96000, 10.0, 1, 256000)])
+def test_single_stream_api_other_geometries(fs, ms, hr, br):
+    amd = _amd()
+    N = int(fs * ms / 1000)
+    pcm = synth_pcm(1, 10, N, fs, seed=9)
+    e = amd.Encoder(fs, 1, ms, hr, br)
+    o = Oracle(fs, 1, ms, hr, br, portable_math=True)
+    for t in range(10):
+        assert (e.encode(pcm[:, t]) == o.encode(pcm[:, t])).all(), t

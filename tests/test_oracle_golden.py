@@ -42,3 +42,18 @@ def test_generator_is_deterministic():
     g = load("c1_48k_10ms_64k")
     pcm = synth_pcm(64, 24, 480, 48000)[g["streams"]]
     assert (pcm == g["pcm"]).all()
+
+
+def _c6():
+    g = load("c6_other_operating_points")
+    for tag in g["tags"]:
+        fs, dms, hr, N = (int(v) for v in g[str(tag) + "_cfg"])
+        yield str(tag), fs, dms / 10.0, hr, N, g[str(tag) + "_rates"], g[str(tag) + "_pcm"], g[str(tag) + "_frames"], g[str(tag) + "_nbytes"]
+
+
+def test_other_operating_points_golden():
+    """one small reference vector per (sample rate, frame length, mode) family outside 48 kHz / 10 ms"""
+    for tag, fs, ms, hr, N, rates, pcm, frames, nbytes in _c6():
+        outs = oracle_encode_streams(pcm, fs, ms, hr, rates)
+        for b, o in enumerate(outs):
+            assert o.shape[1] == nbytes[b] and (o == frames[b][:, :nbytes[b]]).all(), (tag, b)
