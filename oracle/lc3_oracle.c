@@ -1336,3 +1336,5 @@ int lc3o_encode_batch16(int samplerate, float frame_ms, int hrmode, int B, int T
 
 /* test hook: the restated forward DFT on its own (tests/test_oracle_vs_ref.py pins it against the reference's LC3_iisfft_apply) */
 int lc3o_dft(float* x, int n) { float scratch[2 * LC3O_MAX_N]; return dft_any(x, n, scratch); }
+
+#include "lc3_oracle_dec.inc"

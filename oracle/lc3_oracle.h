@@ -19,9 +19,10 @@ extern "C" {
 
 #define LC3O_MAX_N 960
 #define LC3O_MAX_CH 2
+#define LC3O_RESB 640          /* bytes of residual bits kept by the decoder restatement (R/defines.h:118-119 rounds 5000 bits up) */
 
 /* error codes follow R/lc3.h:53-75 */
-enum { LC3O_OK = 0, LC3O_ERROR = 1, LC3O_NULL_ERROR = 3, LC3O_SAMPLERATE_ERROR = 4, LC3O_CHANNELS_ERROR = 5,
+enum { LC3O_OK = 0, LC3O_ERROR = 1, LC3O_DECODE_ERROR = 2, LC3O_NUMBYTES_ERROR = 7, LC3O_NULL_ERROR = 3, LC3O_SAMPLERATE_ERROR = 4, LC3O_CHANNELS_ERROR = 5,
        LC3O_BITRATE_ERROR = 6, LC3O_FRAMEMS_ERROR = 9, LC3O_HRMODE_ERROR = 11, LC3O_BITRATE_SET_ERROR = 13,
        LC3O_HRMODE_BW_ERROR = 14, LC3O_BW_WARNING = 18, LC3O_UNSUPPORTED = 100 };
 
@@ -68,6 +69,14 @@ void lc3o_enc_free(lc3o_enc* e);
 
 /* Convenience for tests / CPU baseline: B independent MONO streams, T frames each.
  * pcm[B][T][N] int16, out[B][T][stride]; per-stream bitrate; returns 0 or an error code. */
+/* decoder restatement (lc3_oracle_dec.inc): R/lc3.h:318-399.  Caller provides lc3o_dec_sizeof() bytes. */
+typedef struct lc3o_dec lc3o_dec;
+int  lc3o_dec_sizeof(void);
+int  lc3o_dec_init(lc3o_dec* d, int samplerate, int channels);
+int  lc3o_dec_set_frame_ms(lc3o_dec* d, float frame_ms);
+int  lc3o_dec_set_hrmode(lc3o_dec* d, int hrmode);
+int  lc3o_dec_get_output_samples(const lc3o_dec* d);
+int  lc3o_dec_frame(lc3o_dec* d, const uint8_t* input, int num_bytes, void** output, int bps, int bfi_ext);   /* 0, LC3O_DECODE_ERROR (concealed) or an error */
 int  lc3o_dft(float* x, int n);      /* test hook: forward complex DFT of length n in place (interleaved re, im); 0 = no kernel */
 int  lc3o_encode_batch16(int samplerate, float frame_ms, int hrmode, int B, int T, const int* bitrate,
                          const int16_t* pcm, uint8_t* out, int stride);

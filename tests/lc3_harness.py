@@ -203,6 +203,31 @@ def ref_encode_streams(pcm, fs, frame_ms, hrmode, bitrates):
     return outs
 
 
+class OracleDecoder:
+    """oracle/lc3_oracle_dec.inc through ctypes (same call shape as RefDecoder)."""
+
+    def __init__(self, fs, channels=1, frame_ms=10.0, hrmode=0, portable_math=False):
+        L = self.lib = C.CDLL(os.path.join(ORACLE_DIR, "liblc3_oracle_pm.so" if portable_math else "liblc3_oracle.so"))
+        L.lc3o_dec_set_frame_ms.argtypes = [C.c_void_p, C.c_float]
+        L.lc3o_dec_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_int]
+        self.buf = C.create_string_buffer(L.lc3o_dec_sizeof() + 8)
+        self.p = C.cast(self.buf, C.c_void_p)
+        self.channels = channels
+        err = L.lc3o_dec_init(self.p, fs, channels)
+        if not err: err = L.lc3o_dec_set_frame_ms(self.p, frame_ms)
+        if not err: err = L.lc3o_dec_set_hrmode(self.p, hrmode)
+        if err:
+            raise RuntimeError("oracle decoder setup error %d" % err)
+        self.N = L.lc3o_dec_get_output_samples(self.p)
+
+    def decode(self, frame_bytes, bfi=0, bps=16):
+        frame_bytes = np.ascontiguousarray(frame_bytes, dtype=np.uint8)
+        out = np.zeros((self.channels, self.N), dtype=np.int16 if bps == 16 else np.int32)
+        ptrs = (C.c_void_p * self.channels)(*[out[c].ctypes.data for c in range(self.channels)])
+        rc = self.lib.lc3o_dec_frame(self.p, frame_bytes.ctypes.data, int(frame_bytes.size), ptrs, bps, bfi)
+        return rc, out
+
+
 class RefDecoder:
     """ETSI float decoder (tool use only: turns bitstreams back into PCM for distance metrics)."""
 
@@ -221,11 +246,12 @@ class RefDecoder:
         self.N = L.lc3_dec_get_output_samples(self.p)
         L.lc3_dec16.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int]
 
-    def decode(self, frame_bytes):
+    def decode(self, frame_bytes, bfi=0, bps=16):
         frame_bytes = np.ascontiguousarray(frame_bytes, dtype=np.uint8)
-        out = np.zeros((self.channels, self.N), dtype=np.int16)
+        out = np.zeros((self.channels, self.N), dtype=np.int16 if bps == 16 else np.int32)
         ptrs = (C.c_void_p * self.channels)(*[out[c].ctypes.data for c in range(self.channels)])
-        rc = self.lib.lc3_dec16(self.p, frame_bytes.ctypes.data, int(frame_bytes.size), ptrs, 0)
+        self.lib.lc3_dec_fl.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_int]
+        rc = self.lib.lc3_dec_fl(self.p, frame_bytes.ctypes.data, int(frame_bytes.size), ptrs, bps, bfi)
         return rc, out
 
     def __del__(self):

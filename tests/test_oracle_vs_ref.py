@@ -133,3 +133,45 @@ def test_soak_every_operating_point_against_the_reference():
         pcm = synth_pcm(64, 40, N, fs, seed=4000)[[0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 62, 63]]     # 62 / 63: the silent and the full-scale stream
         for r, o in zip(ref_encode_streams(pcm, fs, ms, hr, br), oracle_encode_streams(pcm, fs, ms, hr, br)):
             assert (r == o).all(), (fs, ms, hr)
+
+
+def _soak_cfgs():
+    cfg = []
+    for fs in (8000, 16000, 24000, 32000, 44100, 48000):
+        for ms in (10.0, 5.0, 2.5):
+            lo = {10.0: 16000 if fs != 44100 else 32000, 5.0: 32000, 2.5: 64000}[ms]
+            cfg.append((fs, ms, 0, [lo, 2 * lo, 4 * lo, 320000 if fs != 44100 else 256000]))
+    for ms, lo in ((10.0, 124800), (5.0, 148800), (2.5, 172800)):
+        cfg.append((48000, ms, 1, [lo, 256000, 500000]))
+    for ms, lo in ((10.0, 149600), (5.0, 174400), (2.5, 198400)):
+        cfg.append((96000, ms, 1, [lo, 256000, 500000]))
+    return cfg
+
+
+def test_decoder_restatement_equals_the_reference_decoder():
+    """oracle/lc3_oracle_dec.inc against lc3_dec_fl of the compiled reference: decoded PCM sample for sample on every operating-point
+    family, with concealed frames (bfi = 1, and a frame of num_bytes = 0) in the stream, 16- and 24-bit output."""
+    from lc3_harness import OracleDecoder, RefDecoder
+    for fs, ms, hr, rates in _soak_cfgs():
+        N = int(round((48000 if fs == 44100 else fs) * ms / 1000))
+        for bi, br in enumerate(rates):
+            bps = 16 if bi % 2 == 0 else 24
+            enc = Ref(fs, 1, ms, hr, br); rd = RefDecoder(fs, 1, ms, hr); od = OracleDecoder(fs, 1, ms, hr)
+            pcm = synth_pcm(64, 30, N, fs, seed=77)[[3, 5, 62, 63][bi % 4]]
+            for t in range(30):
+                fr = enc.encode(pcm[t:t + 1])
+                bfi = 1 if t in (11, 12, 13, 22) else 0
+                if t == 25: fr = fr[:0]                             # num_bytes = 0 -> bad frame (R/dec_lc3_fl.c:138-141)
+                r1, a = rd.decode(fr, bfi, bps); r2, b = od.decode(fr, bfi, bps)
+                assert r1 == r2 and (a == b).all(), (fs, ms, hr, br, t)
+
+
+def test_decoder_restatement_stereo_and_size_switch():
+    from lc3_harness import OracleDecoder, RefDecoder
+    enc = Ref(48000, 2, 10.0, 0, 128000); rd = RefDecoder(48000, 2, 10.0, 0); od = OracleDecoder(48000, 2, 10.0, 0)
+    pcm = synth_pcm(2, 24, 480, 48000, seed=3)
+    for t in range(24):
+        if t == 12: assert enc.set_bitrate(96001) == 0              # odd total: 60 + 60 bytes; decoders re-derive from num_bytes
+        fr = enc.encode(pcm[:, t])
+        r1, a = rd.decode(fr); r2, b = od.decode(fr)
+        assert r1 == r2 and (a == b).all(), t
