@@ -21,6 +21,12 @@ EXPORTS = [
     "lc3plus_enc_batch_set_bandwidth", "lc3plus_enc_batch_encode", "lc3plus_enc_batch_last_kernel_ms",
     "lc3plus_enc_init", "lc3plus_enc_set_frame_ms", "lc3plus_enc_set_hrmode", "lc3plus_enc_set_bitrate",
     "lc3plus_enc16", "lc3plus_enc_get_size",
+    "lc3_dec_get_size", "lc3_dec_init", "lc3_dec_set_frame_ms", "lc3_dec_set_hrmode", "lc3_dec_get_output_samples",
+    "lc3_dec_get_delay", "lc3_dec_fl", "lc3_dec16", "lc3_dec24", "lc3_dec32", "lc3_dec_free_memory",
+    "lc3_free_decoder_structs",
+    "lc3plus_dec_batch_create", "lc3plus_dec_batch_destroy", "lc3plus_dec_batch_output_samples", "lc3plus_dec_batch_delay",
+    "lc3plus_dec_batch_num_bytes", "lc3plus_dec_batch_set_num_bytes", "lc3plus_dec_batch_decode",
+    "lc3plus_dec_batch_last_kernel_ms",
 ]
 
 
@@ -57,6 +63,24 @@ def load_library():
         L.lc3plus_enc_batch_set_bitrate.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.lc3plus_enc_batch_set_bandwidth.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.lc3_enc_fl.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.POINTER(C.c_int)]
+        L.lc3_dec_set_frame_ms.argtypes = [C.c_void_p, C.c_float]
+        L.lc3_dec_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+        L.lc3_dec_set_hrmode.argtypes = [C.c_void_p, C.c_int]
+        L.lc3_dec_fl.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_int]
+        for f in ("lc3_dec_get_output_samples", "lc3_dec_get_delay", "lc3_free_decoder_structs"):
+            getattr(L, f).argtypes = [C.c_void_p]
+        L.lc3plus_dec_batch_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_float, C.c_int,
+                                               C.POINTER(C.c_int), C.c_int]
+        L.lc3plus_dec_batch_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                               C.c_void_p, C.c_void_p, C.c_int]
+        L.lc3plus_dec_batch_decode_traced.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                                      C.c_void_p, C.c_void_p]
+        L.lc3plus_dec_batch_last_kernel_ms.restype = C.c_float
+        L.lc3plus_dec_batch_last_kernel_ms.argtypes = [C.c_void_p]
+        for f in ("lc3plus_dec_batch_destroy", "lc3plus_dec_batch_output_samples", "lc3plus_dec_batch_delay"):
+            getattr(L, f).argtypes = [C.c_void_p]
+        L.lc3plus_dec_batch_num_bytes.argtypes = [C.c_void_p, C.c_int]
+        L.lc3plus_dec_batch_set_num_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int]
         _LIB = L
     return _LIB
 
@@ -164,6 +188,117 @@ class Encoder:
         if self.p:
             self.lib.lc3_free_encoder_structs(self.p)
             self.p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DecBatch:
+    """n_streams independent decoders (lc3plus_dec_batch_*), state resident on the GPU between decode() calls."""
+
+    def __init__(self, n_streams, samplerate, channels, frame_ms, hrmode, num_bytes, device=-1):
+        self.lib = load_library()
+        nb = (C.c_int * n_streams)(*[int(b) for b in num_bytes])
+        self.h = C.c_void_p()
+        rc = self.lib.lc3plus_dec_batch_create(C.byref(self.h), n_streams, samplerate, channels, frame_ms, hrmode, nb, device)
+        if rc:
+            raise LC3Error(rc, "lc3plus_dec_batch_create")
+        self.n_streams, self.channels = n_streams, channels
+        self.N = self.lib.lc3plus_dec_batch_output_samples(self.h)
+
+    def num_bytes(self, stream):
+        return self.lib.lc3plus_dec_batch_num_bytes(self.h, stream)
+
+    def set_num_bytes(self, stream, nbytes):
+        return self.lib.lc3plus_dec_batch_set_num_bytes(self.h, stream, nbytes)
+
+    def _prep(self, frames, bfi, bps):
+        frames = np.ascontiguousarray(frames, dtype=np.uint8)
+        S, T, stride = frames.shape
+        assert S == self.n_streams
+        if bfi is not None:
+            bfi = np.ascontiguousarray(bfi, dtype=np.uint8)
+            assert bfi.shape == (S, T)
+        pcm = np.zeros((S, T, self.channels, self.N), dtype=np.int16 if bps == 16 else np.int32)
+        status = np.zeros((S, T), dtype=np.uint8)
+        return frames, T, stride, bfi, pcm, status
+
+    def decode(self, frames, bfi=None, bps=16):
+        """frames: uint8 [n_streams, T, stride]; bfi: optional [n_streams, T] -> (pcm [n_streams, T, channels, N], status)."""
+        frames, T, stride, bfi, pcm, status = self._prep(frames, bfi, bps)
+        rc = self.lib.lc3plus_dec_batch_decode(self.h, frames.ctypes.data, 0, stride, bfi.ctypes.data if bfi is not None else None, T,
+                                               pcm.ctypes.data, 0, bps, status.ctypes.data, None, 1)
+        if rc:
+            raise LC3Error(rc, "lc3plus_dec_batch_decode")
+        return pcm, status
+
+    def decode_traced(self, frames, bfi=None, bps=16):
+        frames, T, stride, bfi, pcm, status = self._prep(frames, bfi, bps)
+        tsz = self.lib.lc3plus_dec_trace_sizeof()
+        traces = np.zeros((self.n_streams * self.channels * T, tsz), dtype=np.uint8)
+        rc = self.lib.lc3plus_dec_batch_decode_traced(self.h, frames.ctypes.data, stride, bfi.ctypes.data if bfi is not None else None, T,
+                                                      pcm.ctypes.data, bps, status.ctypes.data, traces.ctypes.data)
+        if rc:
+            raise LC3Error(rc, "lc3plus_dec_batch_decode_traced")
+        return pcm, status, traces
+
+    def decode_device(self, d_frames_ptr, in_stride, T, d_pcm_ptr, bps=16, hip_stream=None, sync=False):
+        """Device-resident variant: raw device pointers, no bad-frame flags."""
+        rc = self.lib.lc3plus_dec_batch_decode(self.h, C.c_void_p(d_frames_ptr), 1, in_stride, None, T, C.c_void_p(d_pcm_ptr), 1, bps, None,
+                                               C.c_void_p(hip_stream) if hip_stream else None, 1 if sync else 0)
+        if rc:
+            raise LC3Error(rc, "lc3plus_dec_batch_decode(device)")
+
+    def last_kernel_ms(self):
+        return float(self.lib.lc3plus_dec_batch_last_kernel_ms(self.h))
+
+    def close(self):
+        if self.h:
+            self.lib.lc3plus_dec_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Decoder:
+    """Single-stream drop-in API (lc3_dec_*), used exactly as R/codec_exe.c uses the reference decoder."""
+
+    def __init__(self, samplerate, channels=1, frame_ms=10.0, hrmode=0):
+        self.lib = load_library()
+        size = self.lib.lc3_dec_get_size(samplerate, channels)
+        if size <= 0:
+            raise LC3Error(1, "lc3_dec_get_size")
+        self.buf = C.create_string_buffer(size)
+        self.h = C.cast(self.buf, C.c_void_p)
+        self.channels = channels
+        for rc, what in ((self.lib.lc3_dec_init(self.h, samplerate, channels, 0), "lc3_dec_init"),
+                         (self.lib.lc3_dec_set_frame_ms(self.h, frame_ms), "lc3_dec_set_frame_ms"),
+                         (self.lib.lc3_dec_set_hrmode(self.h, hrmode), "lc3_dec_set_hrmode")):
+            if rc:
+                raise LC3Error(rc, what)
+        self.N = self.lib.lc3_dec_get_output_samples(self.h)
+
+    def decode(self, frame, bfi_ext=0, bps=16):
+        """frame: bytes of one stream-frame -> (planar samples [channels, N], LC3_Error code 0 or 2)."""
+        data = np.frombuffer(bytes(frame), dtype=np.uint8).copy() if len(frame) else np.zeros(1, dtype=np.uint8)
+        out = np.zeros((self.channels, self.N), dtype=np.int16 if bps == 16 else np.int32)
+        ptrs = (C.c_void_p * self.channels)(*[out[c].ctypes.data for c in range(self.channels)])
+        rc = self.lib.lc3_dec_fl(self.h, data.ctypes.data, len(frame), ptrs, bps, bfi_ext)
+        if rc not in (0, 2):
+            raise LC3Error(rc, "lc3_dec_fl")
+        return out, rc
+
+    def close(self):
+        if self.h:
+            self.lib.lc3_free_decoder_structs(self.h)
+            self.h = None
 
     def __del__(self):
         try:

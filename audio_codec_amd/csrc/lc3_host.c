@@ -49,8 +49,9 @@ static void geom_init(geom_t* g, int samplerate, int channels)            /* R/s
     g->tilt = tilts[g->fs_idx];
 }
 
-static void geom_update(geom_t* g)                                        /* R/setup_enc_lc3.c:73-193 */
+static void geom_update_ex(geom_t* g, int decoder)
 {
+    if (decoder && g->fs_idx == 5) g->hrmode = 1;                        /* the decoder forces hrmode first: R/setup_dec_lc3.c:76-80 */
     g->N = g->fs / 100;
     if (g->hrmode == 1) { g->ylen = g->N; g->sns_damping = 0.6; }
     else { g->ylen = IMIN(400, g->N); g->sns_damping = 0.85; }
@@ -64,6 +65,7 @@ static void geom_update(geom_t* g)                                        /* R/s
         if (lc3t_cfg[i].valid && lc3t_cfg[i].fs_idx == g->fs_idx && lc3t_cfg[i].dms == g->dms && lc3t_cfg[i].hr == g->hrmode) g->tab = &lc3t_cfg[i];
     if (g->tab) { g->nbands = g->tab->nbands; g->la = g->tab->la_zeros; }
 }
+static void geom_update(geom_t* g) { geom_update_ex(g, 0); }              /* R/setup_enc_lc3.c:73-193 */
 
 /* the kernels are built for frame lengths up to LC3D_MAX_N = 960 whose N/2-point DFT has a restated kernel (480 = 15x32, 240 = 15x16,
  * 60 = 4x15, and the prime-factor lengths 10 ... 160) and an MDCT overlap memory of at most 600 samples: every operating point of
@@ -558,3 +560,285 @@ LC3_Error lc3plus_enc_set_hrmode(LC3_Enc* e, int hr) { return lc3_enc_set_hrmode
 LC3_Error lc3plus_enc_set_bitrate(LC3_Enc* e, int br) { return lc3_enc_set_bitrate(e, br); }
 LC3_Error lc3plus_enc16(LC3_Enc* e, int16_t** in, void* out, int* nb) { return lc3_enc16(e, in, out, nb); }
 int lc3plus_enc_get_size(int sr, int ch) { return lc3_enc_get_size(sr, ch); }
+
+
+/* ================================================================================================ */
+/* decoder: lc3_dec_* drop-in API and the batched form                          */
+/* ================================================================================================ */
+/* the decode kernel exists in the standard layout only (frame length <= 480, MDCT memory <= 300) */
+static int dec_geom_supported(const geom_t* g) { return geom_supported(g) && !LC3D_LAYOUT_BIG(g->N, g->la); }
+
+/* R/setup_dec_lc3.c:203-299 (update_dec_bitrate) for one channel */
+static LC3_Error derive_dchan(const geom_t* g, int nbytes, lc3d_dchan* d)
+{
+    int min_b = 20, max_b = 400;                                          /* R/defines.h MIN_NBYTES / MAX_NBYTES */
+    if (g->hrmode) {
+        switch (g->dms) {
+        case 25:  max_b = 210; if (g->fs == 48000) min_b = 54;  else if (g->fs == 96000) min_b = 62;  else return LC3_HRMODE_ERROR; break;
+        case 50:  max_b = 375; if (g->fs == 48000) min_b = 93;  else if (g->fs == 96000) min_b = 109; else return LC3_HRMODE_ERROR; break;
+        case 100: max_b = 625; if (g->fs == 48000) min_b = 156; else if (g->fs == 96000) min_b = 187; else return LC3_HRMODE_ERROR; break;
+        default: return LC3_HRMODE_ERROR;
+        }
+    }
+    if (nbytes < min_b || nbytes > max_b) return LC3_NUMBYTES_ERROR;
+    const int total_bits = nbytes << 3;
+    d->nbytes = nbytes;
+    d->lpc_weighting = total_bits < 480;
+    d->gg_off = -(IMIN(115, total_bits / (10 * (g->fs_idx + 1))) + 105 + 5 * (g->fs_idx + 1));
+    int tb = total_bits;
+    if (g->dms == 25) { d->lpc_weighting = total_bits < 120; tb = (int)(total_bits * 4.0 * (1.0 - 0.4)); }
+    if (g->dms == 50) { d->lpc_weighting = total_bits < 240; tb = total_bits * 2 - 160; }
+    if (g->N > 40 * ((float)g->dms / 10.0)) { d->N_red_tns = (int)(40 * ((float)g->dms / 10.0)); d->fs_red_tns = 40000; }
+    else { d->N_red_tns = g->N; d->fs_red_tns = g->fs; }
+    const int k = (g->fs_idx - 1) * 80;
+    if (tb < 400 + k)      { d->ltpf_beta = 0.4f;  d->ltpf_beta_idx = 0; }
+    else if (tb < 480 + k) { d->ltpf_beta = 0.35f; d->ltpf_beta_idx = 1; }
+    else if (tb < 560 + k) { d->ltpf_beta = 0.3f;  d->ltpf_beta_idx = 2; }
+    else if (tb < 640 + k) { d->ltpf_beta = 0.25f; d->ltpf_beta_idx = 3; }
+    else                   { d->ltpf_beta = 0;     d->ltpf_beta_idx = -1; }
+    if (g->hrmode == 1) { d->ltpf_beta = 0; d->ltpf_beta_idx = -1; }
+    return LC3_OK;
+}
+
+/* split of a stream-frame of num_bytes over the channels (R/dec_lc3_fl.c:148) and the payload offsets */
+static LC3_Error derive_dstream(const geom_t* g, int num_bytes, lc3d_dchan* d /* [channels] */)
+{
+    int off = 0;
+    for (int c = 0; c < g->channels; c++) {
+        LC3_Error e = derive_dchan(g, num_bytes / g->channels + (c < (num_bytes % g->channels)), d + c);
+        if (e) return e;
+        d[c].in_off = off; off += d[c].nbytes;
+    }
+    return LC3_OK;
+}
+
+struct lc3plus_dec_batch {
+    geom_t g; int n_streams;
+    lc3d_dchan* chans;               /* [n_streams * channels] host mirror */
+    void* dev;
+};
+
+LC3_Error lc3plus_dec_batch_create(lc3plus_dec_batch** out, int n_streams, int samplerate, int channels, float frame_ms, int hrmode,
+                                   const int* num_bytes, int device)
+{
+    if (!out) return LC3_NULL_ERROR;
+    *out = NULL;
+    if (n_streams <= 0) return LC3_ERROR;
+    if (!samplerate_ok(samplerate)) return LC3_SAMPLERATE_ERROR;
+    if (channels < 1 || channels > MAX_CH) return LC3_CHANNELS_ERROR;
+    { int d = (int)ceil(frame_ms * 10); if (d != 25 && d != 50 && d != 100) return LC3_FRAMEMS_ERROR; }
+    lc3plus_dec_batch* b = (lc3plus_dec_batch*)calloc(1, sizeof *b);
+    if (!b) return LC3_ERROR;
+    geom_init(&b->g, samplerate, channels);
+    if (b->g.fs_idx < 4 && hrmode != 0) { free(b); return LC3_SAMPLERATE_ERROR; }          /* R/lc3.c:350 */
+    if (b->g.fs_idx == 5 && hrmode == 0) { free(b); return LC3_HRMODE_ERROR; }             /* R/lc3.c:351 */
+    b->g.dms = (int)(frame_ms * 10); b->g.frame_ms = frame_ms; b->g.hrmode = hrmode > 0;
+    geom_update_ex(&b->g, 1);
+    if (!dec_geom_supported(&b->g)) {
+        fprintf(stderr, "lc3plus_hip: decoding %d Hz / %.1f ms%s is not built into the gfx950 kernels yet\n", samplerate, frame_ms, hrmode ? " hr" : "");
+        free(b); return LC3_ERROR;
+    }
+    b->n_streams = n_streams;
+    b->chans = (lc3d_dchan*)calloc((size_t)n_streams * channels, sizeof(lc3d_dchan));
+    if (!b->chans) { free(b); return LC3_ERROR; }
+    if (num_bytes)
+        for (int i = 0; i < n_streams; i++) {
+            LC3_Error e = derive_dstream(&b->g, num_bytes[i], b->chans + (size_t)i * channels);
+            if (e) { free(b->chans); free(b); return e; }
+        }
+    lc3d_plan* plan = (lc3d_plan*)malloc(sizeof *plan);
+    if (!plan) { free(b->chans); free(b); return LC3_ERROR; }
+    build_plan(&b->g, plan);
+    int rc = lc3hip_dec_create(&b->dev, plan, n_streams, device);
+    free(plan);
+    if (!rc) rc = lc3hip_dec_upload_chans(b->dev, b->chans, 0, n_streams * channels);
+    if (rc) { if (b->dev) lc3hip_dec_destroy(b->dev); free(b->chans); free(b); return LC3_ERROR; }
+    *out = b;
+    return LC3_OK;
+}
+
+LC3_Error lc3plus_dec_batch_destroy(lc3plus_dec_batch* b)
+{
+    if (!b) return LC3_NULL_ERROR;
+    lc3hip_dec_destroy(b->dev);
+    free(b->chans); free(b);
+    return LC3_OK;
+}
+
+int lc3plus_dec_batch_output_samples(const lc3plus_dec_batch* b) { return b ? b->g.N : 0; }
+int lc3plus_dec_batch_delay(const lc3plus_dec_batch* b) { return b ? b->g.N - 2 * b->g.la : 0; }
+int lc3plus_dec_batch_num_bytes(const lc3plus_dec_batch* b, int stream)
+{
+    if (!b || stream < 0 || stream >= b->n_streams) return 0;
+    int n = 0;
+    for (int c = 0; c < b->g.channels; c++) n += b->chans[stream * b->g.channels + c].nbytes;
+    return n;
+}
+
+/* frame size change of one stream between decode() calls: what R/dec_lc3_fl.c:149-155 does when num_bytes changes */
+LC3_Error lc3plus_dec_batch_set_num_bytes(lc3plus_dec_batch* b, int stream, int num_bytes)
+{
+    if (!b) return LC3_NULL_ERROR;
+    if (stream < 0 || stream >= b->n_streams) return LC3_ERROR;
+    lc3d_dchan tmp[MAX_CH];
+    memset(tmp, 0, sizeof tmp);
+    LC3_Error e = derive_dstream(&b->g, num_bytes, tmp);
+    if (e) return e;
+    memcpy(b->chans + (size_t)stream * b->g.channels, tmp, sizeof(lc3d_dchan) * b->g.channels);
+    return lc3hip_dec_upload_chans(b->dev, tmp, stream * b->g.channels, b->g.channels) ? LC3_ERROR : LC3_OK;
+}
+
+static LC3_Error dec_batch_decode(lc3plus_dec_batch* b, const void* frames, int frames_on_device, int in_stride, const uint8_t* bfi, int n_frames,
+                                  void* pcm, int pcm_on_device, int bps, uint8_t* status, void* hip_stream, int sync, void* traces)
+{
+    if (!b || !frames || !pcm) return LC3_NULL_ERROR;
+    if (bps != 16 && bps != 24 && bps != 32) return LC3_ERROR;
+    if (n_frames <= 0) return LC3_ERROR;
+    for (int i = 0; i < b->n_streams; i++) if (lc3plus_dec_batch_num_bytes(b, i) > in_stride) return LC3_NUMBYTES_ERROR;
+    return lc3hip_dec_decode(b->dev, frames, frames_on_device, in_stride, bfi, n_frames, pcm, pcm_on_device, bps, status, hip_stream, sync, traces)
+               ? LC3_ERROR : LC3_OK;
+}
+LC3_Error lc3plus_dec_batch_decode(lc3plus_dec_batch* b, const void* frames, int frames_on_device, int in_stride, const uint8_t* bfi, int n_frames,
+                                   void* pcm, int pcm_on_device, int bps, uint8_t* status, void* hip_stream, int sync)
+{
+    return dec_batch_decode(b, frames, frames_on_device, in_stride, bfi, n_frames, pcm, pcm_on_device, bps, status, hip_stream, sync, NULL);
+}
+/* test hook: per channel-stream per frame stage traces (lc3d_dec_trace), host pointers only */
+LC3_Error lc3plus_dec_batch_decode_traced(lc3plus_dec_batch* b, const void* frames, int in_stride, const uint8_t* bfi, int n_frames, void* pcm, int bps,
+                                          uint8_t* status, void* traces)
+{
+    return dec_batch_decode(b, frames, 0, in_stride, bfi, n_frames, pcm, 0, bps, status, NULL, 1, traces);
+}
+int lc3plus_dec_trace_sizeof(void) { return (int)sizeof(lc3d_dec_trace); }
+float lc3plus_dec_batch_last_kernel_ms(lc3plus_dec_batch* b) { return b ? lc3hip_dec_last_ms(b->dev) : 0.0f; }
+
+/* ---- single-stream drop-in API (R/lc3.h:318-406) ---- */
+struct LC3_Dec {
+    int channels, samplerate, plc_mode; float frame_ms;
+    geom_t g;
+    int last_size[MAX_CH];           /* R/setup_dec_lc3.h last_size: bytes of the channel's last good frame */
+    lc3d_dchan ch[MAX_CH];
+    lc3plus_dec_batch* batch;        /* batch of one stream, created lazily at the first decode */
+    uint8_t* stage_in; void* stage_pcm;
+    unsigned magic;
+};
+#define DEC_MAGIC 0x4C433344u
+
+int lc3_dec_get_size(int samplerate, int channels)
+{
+    if (!lc3_samplerate_supported(samplerate) || !lc3_channels_supported(channels)) return 0;
+    return (int)sizeof(struct LC3_Dec);
+}
+
+static void dec_drop_device(LC3_Dec* d)
+{
+    if (d->batch) { lc3plus_dec_batch_destroy(d->batch); d->batch = NULL; }
+    free(d->stage_in); free(d->stage_pcm); d->stage_in = NULL; d->stage_pcm = NULL;
+}
+
+LC3_Error lc3_dec_init(LC3_Dec* d, int samplerate, int channels, LC3_PlcMode plc_mode)
+{
+    if (d == NULL) return LC3_NULL_ERROR;
+    if (!lc3_samplerate_supported(samplerate)) return LC3_SAMPLERATE_ERROR;
+    if (!lc3_channels_supported(channels)) return LC3_CHANNELS_ERROR;
+    if ((int)plc_mode != LC3_PLC_STANDARD) return LC3_PLCMODE_ERROR;      /* R/lc3.c:64-72 */
+    memset(d, 0, sizeof *d);
+    d->magic = DEC_MAGIC; d->channels = channels; d->samplerate = samplerate; d->frame_ms = 10; d->plc_mode = (int)plc_mode;
+    geom_init(&d->g, samplerate, channels);
+    geom_update_ex(&d->g, 1);
+    return LC3_OK;
+}
+
+/* Changing the frame size or hrmode restarts the stream with fresh memories (the reference keeps the old buffers,
+ * R/setup_dec_lc3.c:73-199, whose contents belong to the other frame size; no caller in the reference does this mid-stream) */
+LC3_Error lc3_dec_set_frame_ms(LC3_Dec* d, float frame_ms)
+{
+    if (d == NULL) return LC3_NULL_ERROR;
+    { int k = (int)ceil(frame_ms * 10); if (k != 25 && k != 50 && k != 100) return LC3_FRAMEMS_ERROR; }
+    d->g.dms = (int)(frame_ms * 10); d->g.frame_ms = frame_ms; d->frame_ms = frame_ms;
+    geom_update_ex(&d->g, 1);
+    dec_drop_device(d);
+    memset(d->last_size, 0, sizeof d->last_size); memset(d->ch, 0, sizeof d->ch);
+    return LC3_OK;
+}
+
+LC3_Error lc3_dec_set_hrmode(LC3_Dec* d, int hrmode)
+{
+    if (d == NULL) return LC3_NULL_ERROR;
+    if (d->g.fs_idx < 4 && hrmode != 0) return LC3_SAMPLERATE_ERROR;
+    if (d->g.fs_idx == 5 && hrmode == 0) return LC3_HRMODE_ERROR;
+    d->g.hrmode = hrmode > 0;
+    geom_update_ex(&d->g, 1);
+    dec_drop_device(d);
+    memset(d->last_size, 0, sizeof d->last_size); memset(d->ch, 0, sizeof d->ch);
+    return LC3_OK;
+}
+
+int lc3_dec_get_output_samples(const LC3_Dec* d) { return d ? d->g.N : 0; }
+int lc3_dec_get_delay(const LC3_Dec* d) { return d ? d->g.N - 2 * d->g.la : 0; }
+
+LC3_Error lc3_dec_fl(LC3_Dec* d, void* input_bytes, int num_bytes, void** output_samples, int bps, int bfi_ext)
+{
+    if (!d || !input_bytes || !output_samples) return LC3_NULL_ERROR;
+    for (int c = 0; c < d->channels; c++) if (output_samples[c] == NULL) return LC3_NULL_ERROR;
+    if (bps != 16 && bps != 24 && bps != 32) return LC3_ERROR;
+    if (num_bytes < 0 || num_bytes > LC3_MAX_BYTES) return LC3_NUMBYTES_ERROR;
+    const int N = d->g.N, C = d->channels;
+    if (!d->batch) {
+        LC3_Error err = lc3plus_dec_batch_create(&d->batch, 1, d->g.fs_in, C, d->g.frame_ms, d->g.hrmode, NULL, -1);
+        if (err) return err;
+        d->stage_in = (uint8_t*)malloc(LC3_MAX_BYTES);
+        d->stage_pcm = malloc(sizeof(int32_t) * C * LC3D_MAX_N);
+        if (!d->stage_in || !d->stage_pcm) return LC3_ERROR;
+    }
+    int bfi = bfi_ext;
+    if (bfi == 0) bfi = !num_bytes;                                        /* R/dec_lc3_fl.c:140-143 */
+    if (bfi != 1) {
+        /* R/dec_lc3_fl.c:146-155.  (The reference skips the update of a later channel when an earlier channel of the
+         * SAME frame turns out corrupt; that needs the decode result and is not reproduced: INTEGRATION.md.) */
+        int changed = 0, off = 0;
+        lc3d_dchan tmp[MAX_CH];
+        memcpy(tmp, d->ch, sizeof tmp);
+        for (int c = 0; c < C; c++) {
+            const int nb2 = num_bytes / C + (c < (num_bytes % C));
+            if (nb2 != d->last_size[c]) {
+                LC3_Error e = derive_dchan(&d->g, nb2, &tmp[c]);
+                if (e) return e;
+                changed = 1;
+            }
+            tmp[c].in_off = off; off += tmp[c].nbytes;
+        }
+        if (changed || memcmp(tmp, d->ch, sizeof tmp)) {
+            memcpy(d->ch, tmp, sizeof tmp);
+            for (int c = 0; c < C; c++) d->last_size[c] = d->ch[c].nbytes;
+            memcpy(d->batch->chans, d->ch, sizeof(lc3d_dchan) * C);
+            if (lc3hip_dec_upload_chans(d->batch->dev, d->ch, 0, C)) return LC3_ERROR;
+        }
+    }
+    const int stride = IMAX(num_bytes, lc3plus_dec_batch_num_bytes(d->batch, 0));
+    memset(d->stage_in, 0, LC3_MAX_BYTES);
+    memcpy(d->stage_in, input_bytes, num_bytes);
+    uint8_t flag = (uint8_t)(bfi == 1), status = 0;
+    LC3_Error err = lc3plus_dec_batch_decode(d->batch, d->stage_in, 0, IMAX(stride, 1), &flag, 1, d->stage_pcm, 0, bps, &status, NULL, 1);
+    if (err) return err;
+    const size_t ss = bps == 16 ? 2 : 4;
+    for (int c = 0; c < C; c++) memcpy(output_samples[c], (char*)d->stage_pcm + ss * c * N, ss * N);
+    return status ? LC3_DECODE_ERROR : LC3_OK;
+}
+LC3_Error lc3_dec16(LC3_Dec* d, void* in, int nb, int16_t** out, int bfi_ext) { return lc3_dec_fl(d, in, nb, (void**)out, 16, bfi_ext); }
+LC3_Error lc3_dec24(LC3_Dec* d, void* in, int nb, int32_t** out, int bfi_ext) { return lc3_dec_fl(d, in, nb, (void**)out, 24, bfi_ext); }
+LC3_Error lc3_dec32(LC3_Dec* d, void* in, int nb, int32_t** out, int bfi_ext) { return lc3_dec_fl(d, in, nb, (void**)out, 32, bfi_ext); }
+
+LC3_Error lc3_free_decoder_structs(LC3_Dec* d)
+{
+    if (!d) return LC3_NULL_ERROR;
+    if (d->magic == DEC_MAGIC) dec_drop_device(d);
+    return LC3_OK;
+}
+LC3_Error lc3_dec_free_memory(LC3_Dec* d)
+{
+    if (!d) return LC3_NULL_ERROR;
+    lc3_free_decoder_structs(d);
+    free(d);
+    return LC3_OK;
+}

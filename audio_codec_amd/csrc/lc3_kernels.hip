@@ -767,7 +767,7 @@ __device__ __forceinline__ void dft16_oddblock(const float* O, float* o)
     }
 }
 
-STAGE void mdct_dft240_cols(WaveLds& L, int lane)   /* 15 transforms of length 16, in place in X; two lanes per transform */
+template <class LdsT> STAGE void mdct_dft240_cols(LdsT& L, int lane)   /* 15 transforms of length 16, in place in X; two lanes per transform */
 {
     float* X = XCUR(L);
     const int col = lane >> 1, odd = lane & 1;
@@ -785,7 +785,7 @@ STAGE void mdct_dft240_cols(WaveLds& L, int lane)   /* 15 transforms of length 1
     }
     LSYNC();
 }
-STAGE void mdct_dft240_rows(WaveLds& L, int lane)   /* 16 transforms of length 15, X -> A in natural order */
+template <class LdsT> STAGE void mdct_dft240_rows(LdsT& L, int lane)   /* 16 transforms of length 15, X -> A in natural order */
 {
     const float* X = XCUR(L);
     if (lane < 16) {
@@ -844,7 +844,7 @@ template <bool ODD> __device__ __forceinline__ void dft32_half(float* sd, float*
 }
 /* first stage of the 160-point prime-factor DFT (32 kHz / 10 ms): five 32-point transforms, two lanes each; in place with a barrier.
  * Its own function: it needs more registers than every other DFT stage. */
-STAGE void mdct_dft160_stage1(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
+template <class LdsT> STAGE void mdct_dft160_stage1(const lc3d_plan* __restrict__ P, LdsT& L, int lane)
 {
     float* X = XCUR(L);
     const uint8_t* map = P->pfa_src;
@@ -944,12 +944,12 @@ __device__ __forceinline__ void pfa_stage(const uint8_t* __restrict__ map, const
 }
 /* first stage of the 80-point prime-factor DFT (16 x 5): its own function, so that the 16-point kernel's register needs (and the
  * callee-saved spills they cause) stay out of the other lengths' path */
-STAGE void mdct_dft80_stage1(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
+template <class LdsT> STAGE void mdct_dft80_stage1(const lc3d_plan* __restrict__ P, LdsT& L, int lane)
 {
     float* X = XCUR(L);
     pfa_stage_r<16>(P->pfa_src, nullptr, X, X, 5, lane);
 }
-STAGE void mdct_dft_pfa(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
+template <class LdsT> STAGE void mdct_dft_pfa(const lc3d_plan* __restrict__ P, LdsT& L, int lane)
 {
     float* X = XCUR(L);
     const int len = PI(N) >> 1, nst = PI(pfa_nst);
@@ -966,7 +966,7 @@ STAGE void mdct_dft_pfa(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
 
 /* 60 = 4 x 15 Good-Thomas (R/fft/fft_60_128.h:16-66): four 15-point transforms in place over the map (45k + 16l) % 60, then
  * fifteen 4-point transforms scattering to (15k + 4l) % 60.  X -> A. */
-STAGE void mdct_dft60(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
+template <class LdsT> STAGE void mdct_dft60(const lc3d_plan* __restrict__ P, LdsT& L, int lane)
 {
     float* X = XCUR(L);
     const uint8_t* m = P->pfa_src;                  /* m[k + 4 l] = (45k + 16l) % 60 */
@@ -2601,6 +2601,7 @@ KERNEL_NAME(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans
 /* C-ABI device shim (lc3_shim.h): context, uploads, launch                                          */
 /* ------------------------------------------------------------------------------------------------ */
 #ifndef LC3_BIG                 /* the large-layout object holds only its kernel */
+#include "lc3_dec_kernels.inc"
 extern "C" __global__ void lc3_encode_kernel_big(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans, float* __restrict__ state,
                                                  const void* __restrict__ pcm, int bitdepth, int T, uint8_t* __restrict__ out, int out_stride, int ncs,
                                                  lc3d_trace* __restrict__ trace);
@@ -2723,6 +2724,111 @@ extern "C" int lc3hip_destroy(void* ctx)
     if (c->d_trace) hipFree(c->d_trace);
     hipEventDestroy(c->ev0); hipEventDestroy(c->ev1);
     hipStreamDestroy(c->stream);
+    free(c);
+    return 0;
+}
+/* ---- decoder shim ---- */
+struct lc3hip_dctx {
+    int device, ncs, n_streams, channels, N;
+    lc3d_plan* d_plan; lc3d_dchan* d_chans; float* d_state;
+    uint8_t* d_in; size_t in_cap; void* d_pcm; size_t pcm_cap; uint8_t* d_bfi; size_t bfi_cap;
+    lc3d_dec_trace* d_trace; size_t trace_cap; uint8_t* d_status; size_t status_cap;
+    hipStream_t stream; hipEvent_t ev0, ev1; float last_ms;
+};
+extern "C" int lc3hip_dec_create(void** out_ctx, const lc3d_plan* plan, int n_streams, int device)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { fprintf(stderr, "lc3plus_hip: no HIP device available (this engine has no CPU fallback)\n"); return 1; }
+    lc3hip_dctx* c = (lc3hip_dctx*)calloc(1, sizeof *c);
+    if (!c) return 1;
+    if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
+    c->device = device;
+    HIPCHK(hipSetDevice(device));
+    c->n_streams = n_streams; c->channels = plan->channels; c->ncs = n_streams * plan->channels; c->N = plan->N;
+    HIPCHK(hipMalloc((void**)&c->d_plan, sizeof(lc3d_plan)));
+    HIPCHK(hipMemcpy(c->d_plan, plan, sizeof(lc3d_plan), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc((void**)&c->d_chans, sizeof(lc3d_dchan) * c->ncs));
+    HIPCHK(hipMalloc((void**)&c->d_state, sizeof(float) * DST_WORDS * (size_t)c->ncs));
+    {   /* initial state: zeros; ltpf_mem_beta_idx = -1, cum_alpha = 1, PLC seed 24607 (R/setup_dec_lc3.c:170-183) */
+        float* h = (float*)calloc((size_t)DST_WORDS * c->ncs, sizeof(float));
+        if (!h) return 1;
+        for (int i = 0; i < c->ncs; i++) {
+            int* sc = (int*)(h + (size_t)i * DST_WORDS + DST_SCAL);
+            sc[DS_BETA_IDX] = -1; ((float*)sc)[DS_CUM_ALPHA] = 1.0f; sc[DS_PLC_SEED] = 24607;
+        }
+        hipError_t e = hipMemcpy(c->d_state, h, sizeof(float) * DST_WORDS * (size_t)c->ncs, hipMemcpyHostToDevice);
+        free(h);
+        HIPCHK(e);
+    }
+    HIPCHK(hipStreamCreate(&c->stream));
+    HIPCHK(hipEventCreate(&c->ev0)); HIPCHK(hipEventCreate(&c->ev1));
+    *out_ctx = c;
+    return 0;
+}
+extern "C" int lc3hip_dec_upload_chans(void* ctx, const lc3d_dchan* chans, int first, int count)
+{
+    lc3hip_dctx* c = (lc3hip_dctx*)ctx;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpy(c->d_chans + first, chans, sizeof(lc3d_dchan) * count, hipMemcpyHostToDevice));
+    return 0;
+}
+extern "C" int lc3hip_dec_decode(void* ctx, const void* frames, int frames_on_device, int in_stride, const uint8_t* bfi_host, int n_frames,
+                                 void* pcm, int pcm_on_device, int bps, uint8_t* status_host, void* hip_stream, int sync, void* trace_host)
+{
+    lc3hip_dctx* c = (lc3hip_dctx*)ctx;
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    const size_t in_bytes = (size_t)c->n_streams * n_frames * in_stride;
+    const size_t pcm_bytes = (size_t)c->ncs * n_frames * c->N * (bps == 16 ? 2 : 4);
+    const uint8_t* din = (const uint8_t*)frames; void* dpcm = pcm; const uint8_t* dbfi = nullptr; lc3d_dec_trace* dtr = nullptr;
+    if (!frames_on_device) {
+        if (c->in_cap < in_bytes) { if (c->d_in) HIPCHK(hipFree(c->d_in)); HIPCHK(hipMalloc((void**)&c->d_in, in_bytes)); c->in_cap = in_bytes; }
+        HIPCHK(hipMemcpyAsync(c->d_in, frames, in_bytes, hipMemcpyHostToDevice, s));
+        din = c->d_in;
+    }
+    if (!pcm_on_device) {
+        if (c->pcm_cap < pcm_bytes) { if (c->d_pcm) HIPCHK(hipFree(c->d_pcm)); HIPCHK(hipMalloc((void**)&c->d_pcm, pcm_bytes)); c->pcm_cap = pcm_bytes; }
+        dpcm = c->d_pcm;
+    }
+    if (bfi_host) {
+        const size_t fb = (size_t)c->n_streams * n_frames;
+        if (c->bfi_cap < fb) { if (c->d_bfi) HIPCHK(hipFree(c->d_bfi)); HIPCHK(hipMalloc((void**)&c->d_bfi, fb)); c->bfi_cap = fb; }
+        HIPCHK(hipMemcpyAsync(c->d_bfi, bfi_host, fb, hipMemcpyHostToDevice, s));
+        dbfi = c->d_bfi;
+    }
+    if (trace_host) {
+        const size_t tb = sizeof(lc3d_dec_trace) * (size_t)c->ncs * n_frames;
+        if (c->trace_cap < tb) { if (c->d_trace) HIPCHK(hipFree(c->d_trace)); HIPCHK(hipMalloc((void**)&c->d_trace, tb)); c->trace_cap = tb; }
+        HIPCHK(hipMemsetAsync(c->d_trace, 0, tb, s));
+        dtr = c->d_trace;
+    }
+    uint8_t* dst = nullptr;
+    if (status_host) {
+        const size_t fb = (size_t)c->n_streams * n_frames;
+        if (c->status_cap < fb) { if (c->d_status) HIPCHK(hipFree(c->d_status)); HIPCHK(hipMalloc((void**)&c->d_status, fb)); c->status_cap = fb; }
+        dst = c->d_status;
+    }
+    HIPCHK(hipEventRecord(c->ev0, s));
+    hipLaunchKernelGGL(lc3_decode_kernel, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, din, in_stride, dbfi, n_frames, dpcm, bps, c->ncs, dst, dtr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c->ev1, s));
+    if (!pcm_on_device) HIPCHK(hipMemcpyAsync(pcm, dpcm, pcm_bytes, hipMemcpyDeviceToHost, s));
+    if (trace_host) HIPCHK(hipMemcpyAsync(trace_host, dtr, sizeof(lc3d_dec_trace) * (size_t)c->ncs * n_frames, hipMemcpyDeviceToHost, s));
+    if (status_host) HIPCHK(hipMemcpyAsync(status_host, dst, (size_t)c->n_streams * n_frames, hipMemcpyDeviceToHost, s));
+    if (sync || !pcm_on_device || !frames_on_device || trace_host || bfi_host || status_host) {
+        HIPCHK(hipStreamSynchronize(s));
+        float ms = 0; if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->last_ms = ms;
+    }
+    return 0;
+}
+extern "C" float lc3hip_dec_last_ms(void* ctx) { return ctx ? ((lc3hip_dctx*)ctx)->last_ms : 0.0f; }
+extern "C" int lc3hip_dec_destroy(void* ctx)
+{
+    lc3hip_dctx* c = (lc3hip_dctx*)ctx;
+    if (!c) return 0;
+    hipSetDevice(c->device);
+    hipFree(c->d_plan); hipFree(c->d_chans); hipFree(c->d_state); hipFree(c->d_in); hipFree(c->d_pcm); hipFree(c->d_bfi); hipFree(c->d_trace); hipFree(c->d_status);
+    hipStreamDestroy(c->stream); hipEventDestroy(c->ev0); hipEventDestroy(c->ev1);
     free(c);
     return 0;
 }

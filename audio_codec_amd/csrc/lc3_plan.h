@@ -68,4 +68,22 @@ typedef struct {
 #define LC3D_STATE_WORDS(mc) ((mc) + 660)
 #define LC3D_STATE_WORDS_MAX LC3D_STATE_WORDS(LC3D_MEMCAP_BIG)
 
+/* ---- decoder (lc3_dec_kernels.inc) ---- */
+#define DEC_LY 864                       /* LTPF output history: ceil(228 * 48000 / 12800) + 6 = 861 */
+#define DEC_LX 16                        /* LTPF input history (tilt filter length - 1 <= 10) */
+typedef struct {                         /* per channel-stream decoder configuration, R/setup_dec_lc3.c:188-299 */
+    int32_t nbytes, lpc_weighting, gg_off, N_red_tns, fs_red_tns, ltpf_beta_idx; float ltpf_beta; int32_t in_off;
+} lc3d_dchan;
+
+/* decoder state words per channel-stream */
+#define DST_IMEM   0                                   /* 300: IMDCT overlap memory */
+#define DST_QPREV  300                                 /* 480: last good spectrum (concealment) */
+#define DST_LY     780                                 /* 864: LTPF output history */
+#define DST_LX     (780 + DEC_LY)                      /* 16 : LTPF input history */
+#define DST_SCAL   (780 + DEC_LY + DEC_LX)             /* 16 scalars */
+#define DST_WORDS  (780 + DEC_LY + DEC_LX + 16)
+enum { DS_PITCH_INT = 0, DS_PITCH_FR, DS_BETA_IDX, DS_PARAM0, DS_PARAM1, DS_PARAM2, DS_GAIN /* float */, DS_NBLOST, DS_CUM_ALPHA /* float */, DS_PLC_SEED,
+       DS_PREV_BFI, DS_PREVPREV_BFI };
+
+
 #endif

@@ -13,9 +13,22 @@ typedef struct {
     int nbits, nbits2, lastnz, lsb_mode; int xq[960]; int fac_ns; int n_res_bits; int bp_side, mask_side;
 } lc3d_trace;
 
+/* per decoded channel-frame intermediates; same layout as oracle/lc3_oracle.h: lc3o_dec_trace */
+typedef struct {
+    int bfi, bw_idx, lastnz, lsb_mode, gg_idx, fac_ns, nfilt, tns_order[2], tns_idx[16], scf_idx[7], ltpf[3], nf_seed, zero_frame, nres;
+    int xq[960]; float scf_q[16]; float q_gain[960]; float q_tns[960]; float q_shaped[960]; float x_imdct[960]; float x_out[960];
+} lc3d_dec_trace;
+
+
 #ifdef __cplusplus
 extern "C" {
 #endif
+int   lc3hip_dec_create(void** ctx, const lc3d_plan* plan, int n_streams, int device);
+int   lc3hip_dec_upload_chans(void* ctx, const lc3d_dchan* chans, int first, int count);
+int   lc3hip_dec_decode(void* ctx, const void* frames, int frames_on_device, int in_stride, const uint8_t* bfi_flags_host, int n_frames,
+                        void* pcm, int pcm_on_device, int bps, uint8_t* status_host, void* hip_stream, int sync, void* trace_host);
+float lc3hip_dec_last_ms(void* ctx);
+int   lc3hip_dec_destroy(void* ctx);
 int   lc3hip_create(void** ctx, const lc3d_plan* plan, int n_streams, int device);
 int   lc3hip_reset_state(void* ctx, const float* init_state_one);
 int   lc3hip_upload_chans(void* ctx, const lc3d_chan* chans, int first, int count);

@@ -8,7 +8,9 @@
  * no CPU fallback: if no MI355X / HIP runtime is available the first lc3_enc_* call that needs the device
  * returns LC3_ERROR and prints a diagnostic.
  *
- * Decoder entry points are intentionally absent (decode is out of scope for this engine).
+ * The float decoder (lc3_dec_*, R/lc3.h:318-406) is exported too; it runs in the standard kernel layout
+ * (frame length <= 480 samples and MDCT memory <= 300: every operating point except 96 kHz at 5 and 10 ms).
+ * Error protection (lc3_*_set_ep_*) is not part of the float reference build and has no entry points.
  */
 #ifndef LC3PLUS_HIP_LC3_H
 #define LC3PLUS_HIP_LC3_H
@@ -61,6 +63,29 @@ LC3_Error lc3_enc32(LC3_Enc* encoder, int32_t** input_samples, void* output_byte
  * reference does (R/lc3.c:301-309), so the block must come from malloc().  R/lc3.h:288,295. */
 LC3_Error lc3_enc_free_memory(LC3_Enc* encoder);
 LC3_Error lc3_free_encoder_structs(LC3_Enc* encoder);
+
+/* ---- decoder ---- */
+typedef struct LC3_Dec LC3_Dec;                      /* opaque, caller-allocated: R/lc3.h:116 */
+typedef enum { LC3_PLC_STANDARD = 0, LC3_PLC_ADVANCED = 1 } LC3_PlcMode;   /* R/lc3.h:107-111; only STANDARD is accepted (R/lc3.c:64-72) */
+
+int       lc3_dec_get_size(int samplerate, int channels);                 /* R/lc3.h:359, R/lc3.c:247 */
+LC3_Error lc3_dec_init(LC3_Dec* decoder, int samplerate, int channels, LC3_PlcMode plc_mode);   /* R/lc3.h:318, R/lc3.c:238 */
+LC3_Error lc3_dec_set_frame_ms(LC3_Dec* decoder, float frame_ms);         /* R/lc3.h:368, R/lc3.c:254 */
+LC3_Error lc3_dec_set_hrmode(LC3_Dec* decoder, int hrmode);               /* R/lc3.h:392, R/lc3.c:347 */
+int       lc3_dec_get_output_samples(const LC3_Dec* decoder);             /* R/lc3.h:375, R/lc3.c:265 */
+int       lc3_dec_get_delay(const LC3_Dec* decoder);                      /* R/lc3.h:382, R/lc3.c:271 */
+
+/* One frame: input_bytes holds num_bytes bytes (channel payloads concatenated, split as R/dec_lc3_fl.c:148),
+ * output_samples[ch] receives lc3_dec_get_output_samples() samples of bps 16 (int16_t) or 24/32 (int32_t).
+ * bfi_ext = 1 (or num_bytes = 0) conceals the frame.  Returns LC3_DECODE_ERROR when the frame was concealed
+ * (lost or found corrupt), exactly as R/lc3.c:277-282 -> R/dec_lc3_fl.c:134-163. */
+LC3_Error lc3_dec_fl(LC3_Dec* decoder, void* input_bytes, int num_bytes, void** output_samples, int bps, int bfi_ext);
+LC3_Error lc3_dec16(LC3_Dec* decoder, void* input_bytes, int num_bytes, int16_t** output_samples, int bfi_ext);
+LC3_Error lc3_dec24(LC3_Dec* decoder, void* input_bytes, int num_bytes, int32_t** output_samples, int bfi_ext);
+LC3_Error lc3_dec32(LC3_Dec* decoder, void* input_bytes, int num_bytes, int32_t** output_samples, int bfi_ext);
+
+LC3_Error lc3_dec_free_memory(LC3_Dec* decoder);                          /* R/lc3.h:399, R/lc3.c:311 */
+LC3_Error lc3_free_decoder_structs(LC3_Dec* decoder);                     /* R/lc3.h:406, R/lc3.c:334 */
 
 #ifdef __cplusplus
 }

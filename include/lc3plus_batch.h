@@ -43,6 +43,26 @@ LC3_Error lc3plus_enc_batch_encode(lc3plus_batch* batch, const void* pcm, int pc
 /* Kernel-only timing of the last encode() call in milliseconds (HIP events on the launch stream). */
 float lc3plus_enc_batch_last_kernel_ms(lc3plus_batch* batch);
 
+/* ---- batched decoder: n_streams independent decoder instances, one wavefront per channel-stream; same
+ * conventions as the encoder batch.  num_bytes[n_streams] = bytes per stream-frame (all channels; may be NULL
+ * and set later per stream).  R/dec_lc3_fl.c:134-163 is what one (stream, frame) does. ---- */
+typedef struct lc3plus_dec_batch lc3plus_dec_batch;
+LC3_Error lc3plus_dec_batch_create(lc3plus_dec_batch** batch, int n_streams, int samplerate, int channels,
+                                   float frame_ms, int hrmode, const int* num_bytes, int device);
+LC3_Error lc3plus_dec_batch_destroy(lc3plus_dec_batch* batch);
+int       lc3plus_dec_batch_output_samples(const lc3plus_dec_batch* batch);
+int       lc3plus_dec_batch_delay(const lc3plus_dec_batch* batch);
+int       lc3plus_dec_batch_num_bytes(const lc3plus_dec_batch* batch, int stream);
+LC3_Error lc3plus_dec_batch_set_num_bytes(lc3plus_dec_batch* batch, int stream, int num_bytes);
+/*   frames : [n_streams][n_frames][in_stride] bytes (payload = num_bytes(stream) bytes at the start of each slot)
+ *   bfi    : host pointer, [n_streams][n_frames] bad-frame flags (1 = conceal) or NULL
+ *   pcm    : [n_streams][n_frames][channels][output_samples], int16_t (bps 16) or int32_t (24/32)
+ *   status : host pointer or NULL, [n_streams][n_frames]: 1 where the frame was concealed (LC3_DECODE_ERROR) */
+LC3_Error lc3plus_dec_batch_decode(lc3plus_dec_batch* batch, const void* frames, int frames_on_device, int in_stride,
+                                   const uint8_t* bfi, int n_frames, void* pcm, int pcm_on_device, int bps,
+                                   uint8_t* status, void* hip_stream, int sync);
+float     lc3plus_dec_batch_last_kernel_ms(lc3plus_dec_batch* batch);
+
 /* lc3plus_enc_* spellings of the single-stream API (north-star wording); thin aliases. */
 LC3_Error lc3plus_enc_init(LC3_Enc* e, int samplerate, int channels);
 LC3_Error lc3plus_enc_set_frame_ms(LC3_Enc* e, float frame_ms);

@@ -71,6 +71,18 @@ void lc3o_enc_free(lc3o_enc* e);
  * pcm[B][T][N] int16, out[B][T][stride]; per-stream bitrate; returns 0 or an error code. */
 /* decoder restatement (lc3_oracle_dec.inc): R/lc3.h:318-399.  Caller provides lc3o_dec_sizeof() bytes. */
 typedef struct lc3o_dec lc3o_dec;
+/* intermediate values of one decoded channel-frame (same layout as the device decoder's lc3d_dec_trace) */
+typedef struct {
+    int bfi, bw_idx, lastnz, lsb_mode, gg_idx, fac_ns, nfilt, tns_order[2], tns_idx[16], scf_idx[7], ltpf[3], nf_seed, zero_frame, nres;
+    int xq[LC3O_MAX_N];
+    float scf_q[16];
+    float q_gain[LC3O_MAX_N];       /* after residual decoding, noise filling and the global gain */
+    float q_tns[LC3O_MAX_N];        /* after the TNS synthesis filter */
+    float q_shaped[LC3O_MAX_N];     /* after SNS shaping (the IMDCT input; the concealed spectrum on a lost frame) */
+    float x_imdct[LC3O_MAX_N];      /* time signal before the LTPF */
+    float x_out[LC3O_MAX_N];        /* after the LTPF */
+} lc3o_dec_trace;
+void lc3o_dec_set_trace(lc3o_dec* d, lc3o_dec_trace* tr /* [channels] or NULL */);
 int  lc3o_dec_sizeof(void);
 int  lc3o_dec_init(lc3o_dec* d, int samplerate, int channels);
 int  lc3o_dec_set_frame_ms(lc3o_dec* d, float frame_ms);

@@ -1,0 +1,141 @@
+"""GPU parity tests of the float DECODER (run with -m gpu on an MI355X): lc3_decode_kernel called through the C ABI
+(lc3plus_dec_batch_* / lc3_dec_*) against the CPU oracle decoder (oracle/lc3_oracle_dec.inc, itself pinned
+sample-exact to the unmodified ETSI decoder in tests/test_oracle_vs_ref.py) and against committed decoder outputs of
+the ETSI reference (tests/golden/d*.npz).
+
+Bar: the output PCM is integer data and must be identical sample for sample, for good, lost (bfi = 1) and corrupt
+frames alike, and the per-frame concealment status must agree."""
+import os
+import numpy as np
+import pytest
+
+from lc3_harness import make_dec_case, oracle_decode_streams, Oracle, OracleDecoder, synth_pcm
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _amd():
+    import audio_codec_amd
+    return audio_codec_amd
+
+
+CASES = [
+    (48000, 10.0, 0, [16000, 32000, 64000, 96000, 128000, 192000, 256000, 320000]),
+    (48000, 5.0, 0, [32000, 64000, 96000, 128000, 256000, 320000]),
+    (48000, 2.5, 0, [64000, 96000, 128000, 320000]),
+    (44100, 10.0, 0, [32000, 64000, 128000, 256000]),
+    (44100, 5.0, 0, [64000, 128000]),
+    (32000, 10.0, 0, [32000, 64000, 96000, 128000, 192000, 320000]),
+    (32000, 5.0, 0, [32000, 64000, 96000, 192000]),
+    (32000, 2.5, 0, [64000, 96000, 128000, 256000]),
+    (24000, 10.0, 0, [16000, 32000, 64000, 128000]),
+    (24000, 5.0, 0, [32000, 64000, 96000, 160000]),
+    (24000, 2.5, 0, [64000, 96000, 128000, 256000]),
+    (16000, 10.0, 0, [16000, 32000, 64000, 128000]),
+    (16000, 5.0, 0, [32000, 64000, 96000, 128000]),
+    (16000, 2.5, 0, [64000, 96000, 128000, 192000]),
+    (8000, 10.0, 0, [16000, 24000, 32000, 64000]),
+    (8000, 5.0, 0, [32000, 48000, 64000, 96000]),
+    (8000, 2.5, 0, [64000, 96000, 128000, 160000]),
+    (48000, 10.0, 1, [128000, 256000, 400000, 500000]),
+    (48000, 5.0, 1, [160000, 320000, 600000]),
+    (48000, 2.5, 1, [172800, 256000, 400000]),
+    (96000, 2.5, 1, [256000, 198400, 320000, 672000]),
+]
+
+
+@pytest.mark.parametrize("fs,ms,hr,rates", CASES)
+def test_vs_oracle(fs, ms, hr, rates):
+    T = 30
+    frames, nbytes, bfi = make_dec_case(fs, ms, hr, 1, rates, T, seed=fs // 100 + int(ms * 10) + hr)
+    d = _amd().DecBatch(len(rates), fs, 1, ms, hr, nbytes, device=0)
+    a, sa = d.decode(frames[:, :13], bfi[:, :13])          # two launches: the decoder memories must persist in HBM
+    b, sb = d.decode(frames[:, 13:], bfi[:, 13:])
+    got, status = np.concatenate([a, b], axis=1), np.concatenate([sa, sb], axis=1)
+    want, wstatus = oracle_decode_streams(frames, nbytes, bfi, fs, ms, hr, 1)
+    assert (status == wstatus).all()
+    bad = np.argwhere((got != want).any(axis=(2, 3)))
+    assert len(bad) == 0, ("first differing (stream, frame)", bad[:4].tolist())
+
+
+@pytest.mark.parametrize("bps", [24, 32])
+def test_output_depths(bps):
+    rates = [32000, 64000, 128000, 256000]
+    frames, nbytes, bfi = make_dec_case(48000, 10.0, 0, 1, rates, 12, seed=3)
+    got, status = _amd().DecBatch(len(rates), 48000, 1, 10.0, 0, nbytes, device=0).decode(frames, bfi, bps)
+    want, wstatus = oracle_decode_streams(frames, nbytes, bfi, 48000, 10.0, 0, 1, bps)
+    assert (status == wstatus).all() and (got == want).all()
+
+
+@pytest.mark.parametrize("fs,ms,hr,rates", [(48000, 10.0, 0, [64000, 128000, 256000, 96000]), (32000, 5.0, 0, [64000, 128000]),
+                                            (48000, 2.5, 1, [345600, 512000])])
+def test_stereo_and_error_propagation(fs, ms, hr, rates):
+    """Two channels per stream: the payload split, and a corrupt first channel concealing the second (R/dec_lc3_fl.c:146-160)."""
+    frames, nbytes, bfi = make_dec_case(fs, ms, hr, 2, rates, 24, seed=17, loss=0.1, corrupt=0.3)
+    got, status = _amd().DecBatch(len(rates), fs, 2, ms, hr, nbytes, device=0).decode(frames, bfi)
+    want, wstatus = oracle_decode_streams(frames, nbytes, bfi, fs, ms, hr, 2)
+    assert (status == wstatus).all()
+    assert (got == want).all()
+
+
+def test_long_loss_bursts():
+    """Concealment over bursts longer than the attenuation ramp (R/plc_noise_substitution.c, R/plc_damping_scrambling.c)."""
+    rates = [32000, 96000, 160000]
+    frames, nbytes, _ = make_dec_case(48000, 10.0, 0, 1, rates, 40, seed=5, loss=0, corrupt=0)
+    bfi = np.zeros((3, 40), dtype=np.uint8)
+    bfi[0, 5:25] = 1; bfi[1, 0:4] = 1; bfi[1, 20:23] = 1; bfi[2, 10:40] = 1
+    got, status = _amd().DecBatch(3, 48000, 1, 10.0, 0, nbytes, device=0).decode(frames, bfi)
+    want, wstatus = oracle_decode_streams(frames, nbytes, bfi, 48000, 10.0, 0, 1)
+    assert (status == bfi).all() and (wstatus == bfi).all()
+    assert (got == want).all()
+
+
+def test_single_stream_api_with_rate_switch_and_empty_frames():
+    """lc3_dec_fl as R/codec_exe.c drives it: frame size changes mid-stream (R/dec_lc3_fl.c:149-155), num_bytes = 0 means lost."""
+    amd = _amd()
+    N, T = 480, 36
+    pcm = synth_pcm(1, T, N, 48000, seed=9)[0]
+    enc = Oracle(48000, 1, 10.0, 0, 64000)
+    frames = []
+    for t in range(T):
+        if t == 12: enc.set_bitrate(128000)
+        if t == 24: enc.set_bitrate(32000)
+        frames.append(enc.encode(pcm[t][None]))
+    d = amd.Decoder(48000, 1, 10.0, 0)
+    o = OracleDecoder(48000, 1, 10.0, 0, portable_math=True)
+    for t in range(T):
+        f, bfi = frames[t], 0
+        if t in (7, 8, 25): f = np.zeros(0, dtype=np.uint8)
+        if t == 15: bfi = 1
+        got, rc = d.decode(f.tobytes(), bfi)
+        wrc, want = o.decode(f if f.size else np.zeros(1, dtype=np.uint8), bfi, num_bytes=int(f.size))
+        assert rc == wrc, (t, rc, wrc)
+        assert (got == want).all(), t
+    d.close()
+
+
+def test_roundtrip_with_gpu_encoder_large():
+    """Size-independent property at a large batch: GPU encode -> GPU decode reproduces the input closely (delay compensated),
+    and a sample of the streams equals the oracle decoder exactly."""
+    amd = _amd()
+    B, T, N = 2048, 20, 480
+    pcm = synth_pcm(B, T, N, 48000, seed=31)
+    enc = amd.Batch(B, 48000, 1, 10.0, 0, [128000] * B, device=0)
+    frames = enc.encode(pcm)
+    nb = enc.num_bytes(0)
+    dec = amd.DecBatch(B, 48000, 1, 10.0, 0, [nb] * B, device=0)
+    out, status = dec.decode(frames)
+    assert status.sum() == 0
+    x = pcm.reshape(B, -1).astype(np.float64)
+    y = out.reshape(B, -1).astype(np.float64)
+    best = None
+    for lag in (120, 240, 300, 480):   # codec delay candidates; lc3_enc_get_delay + lc3_dec_get_delay is one of them
+        e = ((x[:, N:-N - lag] - y[:, N + lag:y.shape[1] - N]) ** 2).sum(axis=1)
+        s = (x[:, N:-N - lag] ** 2).sum(axis=1)
+        snr = 10 * np.log10(np.maximum(s, 1e-9) / np.maximum(e, 1e-9))
+        best = snr if best is None or snr.mean() > best.mean() else best
+    assert np.median(best) > 15.0, np.median(best)
+    pick = [0, 1, 777, 2047]
+    want, _ = oracle_decode_streams(frames[pick], [nb] * len(pick), None, 48000, 10.0, 0, 1)
+    assert (out[pick] == want).all()
