@@ -27,6 +27,9 @@ WORKLOADS = {
     "c3": (48000, 10.0, 0, 2, 480, [128000], 16),
     "c4": (96000, 2.5, 1, 1, 240, [256000], 256),
     "c5": (48000, 10.0, 0, 1, 480, [16000, 24000, 32000, 48000, 64000, 80000, 96000, 128000, 160000, 192000, 256000, 320000], 64),
+    # decoder: the C1 / C5 bitstreams, produced on the GPU just before, decoded back to 16-bit PCM
+    "d1": (48000, 10.0, 0, 1, 480, [64000], 64),
+    "d5": (48000, 10.0, 0, 1, 480, [16000, 24000, 32000, 48000, 64000, 80000, 96000, 128000, 160000, 192000, 256000, 320000], 64),
 }
 HBM_PEAK_GBS = 8000.0                          # MI355X_MICROARCH.md: 8.0 TB/s spec
 
@@ -108,17 +111,26 @@ def other_workload(a):
     stride = batch.stride
     out = torch.zeros(B, T, stride, dtype=torch.uint8, device=dev)
     stream = torch.cuda.current_stream(dev)
-    for _ in range(a.warmup): batch.encode_device(pcm.data_ptr(), 16, T, out.data_ptr(), stride, hip_stream=stream.cuda_stream)
+    if a.workload.startswith("d"):
+        batch.encode_device(pcm.data_ptr(), 16, T, out.data_ptr(), stride, hip_stream=stream.cuda_stream, sync=True)
+        dec = audio_codec_amd.DecBatch(B, fs, ch, ms, hr, [batch.num_bytes(i) for i in range(B)], device=0)
+        back = torch.zeros(B, T, ch, n, dtype=torch.int16, device=dev)
+        run = lambda: dec.decode_device(out.data_ptr(), stride, T, back.data_ptr(), 16, hip_stream=stream.cuda_stream)
+        what = "decoded"
+    else:
+        run = lambda: batch.encode_device(pcm.data_ptr(), 16, T, out.data_ptr(), stride, hip_stream=stream.cuda_stream)
+        what = "encoded"
+    for _ in range(a.warmup): run()
     torch.cuda.synchronize(dev)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter(); e0.record(stream)
-    for _ in range(a.steps): batch.encode_device(pcm.data_ptr(), 16, T, out.data_ptr(), stride, hip_stream=stream.cuda_stream)
+    for _ in range(a.steps): run()
     e1.record(stream); torch.cuda.synchronize(dev)
     wall = time.perf_counter() - t0
     nbytes = [batch.num_bytes(i) for i in range(min(B, len(rates)))]
     algo = B * T * (2 * n * ch) + T * sum(batch.num_bytes(i) for i in range(B))
     kern_ms = e0.elapsed_time(e1) / a.steps
-    print(json.dumps({"metric": "Mframes/s encoded (channel-frames)", "value": round(B * T * ch * a.steps / wall / 1e6, 4), "unit": "Mframes/s",
+    print(json.dumps({"metric": "Mframes/s %s (channel-frames)" % what, "value": round(B * T * ch * a.steps / wall / 1e6, 4), "unit": "Mframes/s",
                       "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(wall / a.steps * 1e3, 4), "higher_is_better": True,
                       "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                       "config": {"workload": "%s: %d streams x %d frames, %d Hz / %.1f ms%s, %d ch, bytes/frame %s" % (a.workload, B, T, fs, ms, " hr" if hr else "", ch, nbytes)},

@@ -276,7 +276,7 @@ class RefDecoder:
             pass
 
 
-def make_dec_case(fs, frame_ms, hrmode, channels, rates, T, seed=7, loss=0.15, corrupt=0.1):
+def make_dec_case(fs, frame_ms, hrmode, channels, rates, T, seed=7, loss=0.15, corrupt=0.1, enc_cls=None):
     """Encodes seeded synthetic PCM with the CPU oracle (one encoder per stream) and damages the result:
     returns frames uint8 [B, T, stride], nbytes [B], bfi uint8 [B, T].  `loss` marks frames as lost (bfi = 1),
     `corrupt` flips bytes inside frames that are NOT marked, so the decoder has to find the damage itself."""
@@ -286,7 +286,7 @@ def make_dec_case(fs, frame_ms, hrmode, channels, rates, T, seed=7, loss=0.15, c
     pcm = synth_pcm(B * channels, T, N, fs, seed=seed).reshape(B, channels, T, N).transpose(0, 2, 1, 3)
     per = []
     for b in range(B):
-        o = Oracle(fs, channels, frame_ms, hrmode, int(rates[b]))
+        o = (enc_cls or Oracle)(fs, channels, frame_ms, hrmode, int(rates[b]))
         per.append(np.stack([o.encode(pcm[b, t]) for t in range(T)]))
     nbytes = [p.shape[1] for p in per]
     frames = np.zeros((B, T, max(nbytes)), dtype=np.uint8)

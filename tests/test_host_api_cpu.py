@@ -106,3 +106,57 @@ def test_batch_argument_validation(lib):
     assert f(C.byref(h), 2, 96000, 1, 10.0, 0, br, -1) == 6      # 96 kHz forces hrmode (R/setup_enc_lc3.c:93-96); 64 kbps is below the hrmode minimum
     bad = (C.c_int * 2)(64000, 1000)
     assert f(C.byref(h), 2, 48000, 1, 10.0, 0, bad, -1) in (1, 6)   # bitrate error (6) unless no device was found first (1)
+
+
+def test_decoder_configuration_matches_reference_derivation(lib):
+    """lc3_dec_init / set_frame_ms / set_hrmode error codes and derived sizes (R/lc3.c:238-275,347-356, R/setup_dec_lc3.c:71-185)
+    against the oracle restatement of the decoder, which is pinned to the compiled reference."""
+    o = _oracle()
+    o.lc3o_dec_set_frame_ms.argtypes = [C.c_void_p, C.c_float]
+    lib.lc3_dec_get_delay.argtypes = [C.c_void_p]
+    for fs in (8000, 16000, 24000, 32000, 44100, 48000, 96000, 22050):
+        for ch in (1, 2, 3):
+            for ms in (2.5, 5.0, 10.0, 7.5):
+                for hr in (0, 1):
+                    size = lib.lc3_dec_get_size(fs, ch)
+                    ok_cfg = fs != 22050 and ch <= 2
+                    assert (size > 0) == ok_cfg
+                    pb = C.create_string_buffer(max(size, 64)); p = C.cast(pb, C.c_void_p)
+                    ob = C.create_string_buffer(o.lc3o_dec_sizeof()); q = C.cast(ob, C.c_void_p)
+                    got = [lib.lc3_dec_init(p, fs, ch, 0)]
+                    want = [o.lc3o_dec_init(q, fs, ch)]
+                    assert got == want, (fs, ch, got, want)
+                    if got[0]:
+                        continue
+                    got += [lib.lc3_dec_set_frame_ms(p, ms), lib.lc3_dec_set_hrmode(p, hr)]
+                    want += [o.lc3o_dec_set_frame_ms(q, ms), o.lc3o_dec_set_hrmode(q, hr)]
+                    assert got == want, (fs, ch, ms, hr, got, want)
+                    assert lib.lc3_dec_get_output_samples(p) == o.lc3o_dec_get_output_samples(q), (fs, ms, hr)
+                    lib.lc3_free_decoder_structs(p)
+    assert lib.lc3_dec_init(None, 48000, 1, 0) == 3
+    pb = C.create_string_buffer(lib.lc3_dec_get_size(48000, 1)); p = C.cast(pb, C.c_void_p)
+    assert lib.lc3_dec_init(p, 48000, 1, 1) == 15                   # LC3_PLCMODE_ERROR: only LC3_PLC_STANDARD (R/lc3.c:64-72)
+    assert lib.lc3_dec_init(p, 48000, 1, 0) == 0
+    assert lib.lc3_dec_get_delay(p) == 480 - 2 * 180
+    assert lib.lc3_dec_fl(p, None, 10, None, 16, 0) == 3
+
+
+def test_decoder_batch_argument_validation_and_no_fallback(lib):
+    h = C.c_void_p()
+    nb = (C.c_int * 2)(80, 80)
+    f = lib.lc3plus_dec_batch_create
+    assert f(C.byref(h), 2, 12345, 1, 10.0, 0, nb, -1) == 4
+    assert f(C.byref(h), 2, 48000, 3, 10.0, 0, nb, -1) == 5
+    assert f(C.byref(h), 2, 48000, 1, 7.5, 0, nb, -1) == 9
+    assert f(C.byref(h), 2, 32000, 1, 10.0, 1, nb, -1) == 4
+    assert f(C.byref(h), 2, 96000, 1, 2.5, 0, nb, -1) == 11         # LC3_HRMODE_ERROR (R/lc3.c:351)
+    bad = (C.c_int * 2)(80, 5)
+    assert f(C.byref(h), 2, 48000, 1, 10.0, 0, bad, -1) == 7        # LC3_NUMBYTES_ERROR (R/setup_dec_lc3.c:245-248)
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(audio_codec_amd.LC3Error):
+        audio_codec_amd.DecBatch(2, 48000, 1, 10.0, 0, [80, 80])
+    d = audio_codec_amd.Decoder(48000, 1, 10.0, 0)                  # configuration works on the host, decoding needs the HIP path
+    with pytest.raises(audio_codec_amd.LC3Error):
+        d.decode(bytes(80))

@@ -57,3 +57,22 @@ def test_other_operating_points_golden():
         outs = oracle_encode_streams(pcm, fs, ms, hr, rates)
         for b, o in enumerate(outs):
             assert o.shape[1] == nbytes[b] and (o == frames[b][:, :nbytes[b]]).all(), (tag, b)
+
+
+def _d1():
+    g = load("d1_decoder_operating_points")
+    for tag in g["tags"]:
+        tag = str(tag)
+        fs, dms, hr, ch = (int(v) for v in g[tag + "_cfg"])
+        yield tag, fs, dms / 10.0, hr, ch, g[tag + "_frames"], g[tag + "_nbytes"], g[tag + "_bfi"], g[tag + "_pcm"], g[tag + "_status"]
+
+
+@pytest.mark.parametrize("portable", [False, True])
+def test_decoder_golden(portable):
+    """the decoder restatement against what the unmodified ETSI decoder made of damaged bitstreams (lost and corrupt frames included):
+    PCM sample for sample and the concealment status, on every fixture operating point, with either math build"""
+    from lc3_harness import oracle_decode_streams
+    for tag, fs, ms, hr, ch, frames, nbytes, bfi, pcm, status in _d1():
+        got, st = oracle_decode_streams(frames, nbytes, bfi, fs, ms, hr, ch, portable_math=portable)
+        assert (st == status).all(), tag
+        assert (got == pcm).all(), (tag, np.argwhere((got != pcm).any(axis=(2, 3)))[:3].tolist())

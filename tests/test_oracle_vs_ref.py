@@ -175,3 +175,46 @@ def test_decoder_restatement_stereo_and_size_switch():
         fr = enc.encode(pcm[:, t])
         r1, a = rd.decode(fr); r2, b = od.decode(fr)
         assert r1 == r2 and (a == b).all(), t
+
+
+def test_decoder_api_error_codes_match():
+    """lc3_dec_init / set_frame_ms / set_hrmode / get_output_samples of the compiled reference (R/lc3.c:238-275,347-356) against the
+    decoder restatement, over supported and unsupported arguments."""
+    import ctypes as C
+    from lc3_harness import REF_SO, ORACLE_DIR
+    R = C.CDLL(REF_SO); O = C.CDLL(os.path.join(ORACLE_DIR, "liblc3_oracle.so"))
+    R.lc3_dec_set_frame_ms.argtypes = [C.c_void_p, C.c_float]; O.lc3o_dec_set_frame_ms.argtypes = [C.c_void_p, C.c_float]
+    for fs in (8000, 16000, 24000, 32000, 44100, 48000, 96000, 22050):
+        for ch in (0, 1, 2, 3):
+            rb = C.create_string_buffer(max(R.lc3_dec_get_size(48000, 2), 64) + 8); r = C.cast(rb, C.c_void_p)
+            ob = C.create_string_buffer(O.lc3o_dec_sizeof() + 8); o = C.cast(ob, C.c_void_p)
+            a, b = R.lc3_dec_init(r, fs, ch, 0), O.lc3o_dec_init(o, fs, ch)
+            assert a == b, (fs, ch, a, b)
+            if a:
+                continue
+            for ms in (2.5, 5.0, 10.0, 7.5):
+                for hr in (0, 1):
+                    a = [R.lc3_dec_set_frame_ms(r, ms), R.lc3_dec_set_hrmode(r, hr), R.lc3_dec_get_output_samples(r)]
+                    b = [O.lc3o_dec_set_frame_ms(o, ms), O.lc3o_dec_set_hrmode(o, hr), O.lc3o_dec_get_output_samples(o)]
+                    assert a == b, (fs, ch, ms, hr, a, b)
+            R.lc3_free_decoder_structs(r)
+
+
+def test_decoder_portable_math_boundary_at_24_bits():
+    """The portable-math build of the decoder restatement (what the HIP kernels compute: libm calls as (float)f((double)x)) against the
+    reference decoder with 24-bit output, where a different rounding of one powf() shows as one output LSB: at most 1 LSB apart,
+    and identical in more than 99.9 % of the samples.  (With the glibc-math build the outputs are identical: tests above.)"""
+    from lc3_harness import OracleDecoder, RefDecoder
+    tot = same = 0
+    for fs, ms, ch, br in ((48000, 5.0, 2, 128000), (48000, 10.0, 1, 96000), (32000, 10.0, 1, 64000)):
+        N = int(fs * ms / 1000)
+        enc = Ref(fs, ch, ms, 0, br); rd = RefDecoder(fs, ch, ms, 0); od = OracleDecoder(fs, ch, ms, 0, portable_math=True)
+        pcm = synth_pcm(ch, 40, N, fs, seed=41)
+        for t in range(40):
+            fr = enc.encode(pcm[:, t])
+            bfi = 1 if t % 11 in (3, 8, 9) else 0
+            r1, a = rd.decode(fr, bfi, 24); r2, b = od.decode(fr, bfi, 24)
+            assert r1 == r2
+            assert np.abs(a.astype(np.int64) - b).max() <= 1, (fs, ms, t)
+            tot += a.size; same += int((a == b).sum())
+    assert same > 0.999 * tot, (same, tot)
