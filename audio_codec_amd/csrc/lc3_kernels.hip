@@ -2601,6 +2601,7 @@ KERNEL_NAME(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans
 /* C-ABI device shim (lc3_shim.h): context, uploads, launch                                          */
 /* ------------------------------------------------------------------------------------------------ */
 #ifndef LC3_BIG                 /* the large-layout object holds only its kernel */
+#include "lc3_dec_parse.inc"
 #include "lc3_dec_kernels.inc"
 extern "C" __global__ void lc3_encode_kernel_big(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans, float* __restrict__ state,
                                                  const void* __restrict__ pcm, int bitdepth, int T, uint8_t* __restrict__ out, int out_stride, int ncs,
@@ -2733,6 +2734,7 @@ struct lc3hip_dctx {
     lc3d_plan* d_plan; lc3d_dchan* d_chans; float* d_state;
     uint8_t* d_in; size_t in_cap; void* d_pcm; size_t pcm_cap; uint8_t* d_bfi; size_t bfi_cap;
     lc3d_dec_trace* d_trace; size_t trace_cap; uint8_t* d_status; size_t status_cap;
+    int* d_rec; float* d_ws; size_t hand_cap; int max_nbytes;
     hipStream_t stream; hipEvent_t ev0, ev1; float last_ms;
 };
 extern "C" int lc3hip_dec_create(void** out_ctx, const lc3d_plan* plan, int n_streams, int device)
@@ -2770,6 +2772,7 @@ extern "C" int lc3hip_dec_upload_chans(void* ctx, const lc3d_dchan* chans, int f
     lc3hip_dctx* c = (lc3hip_dctx*)ctx;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpy(c->d_chans + first, chans, sizeof(lc3d_dchan) * count, hipMemcpyHostToDevice));
+    for (int i = 0; i < count; i++) if (chans[i].nbytes > c->max_nbytes) c->max_nbytes = chans[i].nbytes;
     return 0;
 }
 extern "C" int lc3hip_dec_decode(void* ctx, const void* frames, int frames_on_device, int in_stride, const uint8_t* bfi_host, int n_frames,
@@ -2808,8 +2811,27 @@ extern "C" int lc3hip_dec_decode(void* ctx, const void* frames, int frames_on_de
         if (c->status_cap < fb) { if (c->d_status) HIPCHK(hipFree(c->d_status)); HIPCHK(hipMalloc((void**)&c->d_status, fb)); c->status_cap = fb; }
         dst = c->d_status;
     }
+    {   /* hand-over buffers between the two kernels: records and spectrum rows of every channel-frame of this call */
+        const size_t cf = (size_t)c->ncs * n_frames;
+        if (c->hand_cap < cf) {
+            if (c->d_rec) HIPCHK(hipFree(c->d_rec));
+            if (c->d_ws) HIPCHK(hipFree(c->d_ws));
+            c->d_rec = nullptr; c->d_ws = nullptr; c->hand_cap = 0;
+            HIPCHK(hipMalloc((void**)&c->d_rec, cf * PR_WORDS * sizeof(int)));
+            HIPCHK(hipMalloc((void**)&c->d_ws, cf * WS_ROW * sizeof(float)));
+            c->hand_cap = cf;
+        }
+    }
+    const int nw_max = c->max_nbytes > 0 ? (c->max_nbytes + 3) / 4 : 1;
+    const size_t dyn = (size_t)nw_max * WAVE * sizeof(unsigned);
+    if (dyn + sizeof(ParseLds) > 64 * 1024) { fprintf(stderr, "lc3plus_hip: frame of %d bytes exceeds the parse kernel's LDS staging\n", c->max_nbytes); return 1; }
+    const long long tasks = (long long)c->n_streams * n_frames;
     HIPCHK(hipEventRecord(c->ev0, s));
-    hipLaunchKernelGGL(lc3_decode_kernel, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, din, in_stride, dbfi, n_frames, dpcm, bps, c->ncs, dst, dtr);
+    /* kernel 1: one stream-frame per lane (stateless stages); kernel 2: one wave per channel-stream (stateful stages) */
+    hipLaunchKernelGGL(lc3_dec_parse_kernel, dim3((unsigned)((tasks + WAVE - 1) / WAVE)), dim3(WAVE), dyn, s, c->d_plan, c->d_chans, din, in_stride, dbfi, n_frames,
+                       c->n_streams, nw_max, c->d_rec, c->d_ws);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(lc3_decode_kernel, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, c->d_rec, c->d_ws, n_frames, dpcm, bps, c->ncs, dst, dtr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev1, s));
     if (!pcm_on_device) HIPCHK(hipMemcpyAsync(pcm, dpcm, pcm_bytes, hipMemcpyDeviceToHost, s));
@@ -2827,7 +2849,7 @@ extern "C" int lc3hip_dec_destroy(void* ctx)
     lc3hip_dctx* c = (lc3hip_dctx*)ctx;
     if (!c) return 0;
     hipSetDevice(c->device);
-    hipFree(c->d_plan); hipFree(c->d_chans); hipFree(c->d_state); hipFree(c->d_in); hipFree(c->d_pcm); hipFree(c->d_bfi); hipFree(c->d_trace); hipFree(c->d_status);
+    hipFree(c->d_plan); hipFree(c->d_chans); hipFree(c->d_state); hipFree(c->d_in); hipFree(c->d_pcm); hipFree(c->d_bfi); hipFree(c->d_trace); hipFree(c->d_status); hipFree(c->d_rec); hipFree(c->d_ws);
     hipStreamDestroy(c->stream); hipEventDestroy(c->ev0); hipEventDestroy(c->ev1);
     free(c);
     return 0;
