@@ -65,7 +65,7 @@ def main():
                 g = DecTrace.from_buffer_copy(traces[(b * CH + c) * T + t].tobytes()[:C.sizeof(DecTrace)])
                 cc = tr[c]
                 for f, _ in DecTrace._fields_:
-                    if f in ("bfi", "xq", "q_gain"):      # the first kernel hands over the spectrum after TNS only
+                    if f in ("bfi", "xq", "q_gain", "scf_q"):      # the first kernel hands over the spectrum after TNS only
                         continue
                     ga, ca = getattr(g, f), getattr(cc, f)
                     if hasattr(ga, "__len__"):
