@@ -565,8 +565,8 @@ int lc3plus_enc_get_size(int sr, int ch) { return lc3_enc_get_size(sr, ch); }
 /* ================================================================================================ */
 /* decoder: lc3_dec_* drop-in API and the batched form                          */
 /* ================================================================================================ */
-/* the decode kernel exists in the standard layout only (frame length <= 480, MDCT memory <= 300) */
-static int dec_geom_supported(const geom_t* g) { return geom_supported(g) && !LC3D_LAYOUT_BIG(g->N, g->la); }
+/* same operating points as the encoder: standard and large kernel layout */
+static int dec_geom_supported(const geom_t* g) { return geom_supported(g); }
 
 /* R/setup_dec_lc3.c:203-299 (update_dec_bitrate) for one channel */
 static LC3_Error derive_dchan(const geom_t* g, int nbytes, lc3d_dchan* d)

@@ -874,7 +874,7 @@ template <class LdsT> STAGE void mdct_dft160_stage1(const lc3d_plan* __restrict_
 /* 480 = 15 x 32 Good-Thomas (R/fft/fft_240_480.h:90-185): index tables table1[k + 15 l] = (256 k + 225 l) mod 480 for the fifteen
  * 32-point column transforms (two lanes each, in place), the same table as (225 k + 256 l) mod 480 for the thirty-two 15-point row
  * transforms, output table2[15 k + l] = (15 k + 32 l) mod 480.  X -> A. */
-STAGE void mdct_dft480_cols(WaveLds& L, int lane)
+template <class LdsT> STAGE void mdct_dft480_cols(LdsT& L, int lane)
 {
     float* X = XCUR(L);
     const bool on = lane < 30;
@@ -898,7 +898,7 @@ STAGE void mdct_dft480_cols(WaveLds& L, int lane)
     }
     LSYNC();
 }
-STAGE void mdct_dft480_rows(WaveLds& L, int lane)
+template <class LdsT> STAGE void mdct_dft480_rows(LdsT& L, int lane)
 {
     const float* X = XCUR(L);
     if (lane < 32) {
@@ -2600,9 +2600,9 @@ KERNEL_NAME(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans
 /* ------------------------------------------------------------------------------------------------ */
 /* C-ABI device shim (lc3_shim.h): context, uploads, launch                                          */
 /* ------------------------------------------------------------------------------------------------ */
-#ifndef LC3_BIG                 /* the large-layout object holds only its kernel */
+#include "lc3_dec_kernels.inc"     /* lc3_decode_kernel, or lc3_decode_kernel_big in the large-layout object */
+#ifndef LC3_BIG                 /* the large-layout object holds only its kernels */
 #include "lc3_dec_parse.inc"
-#include "lc3_dec_kernels.inc"
 extern "C" __global__ void lc3_encode_kernel_big(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans, float* __restrict__ state,
                                                  const void* __restrict__ pcm, int bitdepth, int T, uint8_t* __restrict__ out, int out_stride, int ncs,
                                                  lc3d_trace* __restrict__ trace);
@@ -2729,8 +2729,11 @@ extern "C" int lc3hip_destroy(void* ctx)
     return 0;
 }
 /* ---- decoder shim ---- */
+extern "C" __global__ void lc3_decode_kernel_big(const lc3d_plan* __restrict__ P, const lc3d_dchan* __restrict__ chans, float* __restrict__ state,
+                                                 const int* __restrict__ rec, const float* __restrict__ ws, int T, void* __restrict__ pcm, int bps, int ncs,
+                                                 uint8_t* __restrict__ status, lc3d_dec_trace* __restrict__ trace);
 struct lc3hip_dctx {
-    int device, ncs, n_streams, channels, N;
+    int device, ncs, n_streams, channels, N, big;
     lc3d_plan* d_plan; lc3d_dchan* d_chans; float* d_state;
     uint8_t* d_in; size_t in_cap; void* d_pcm; size_t pcm_cap; uint8_t* d_bfi; size_t bfi_cap;
     lc3d_dec_trace* d_trace; size_t trace_cap; uint8_t* d_status; size_t status_cap;
@@ -2747,6 +2750,7 @@ extern "C" int lc3hip_dec_create(void** out_ctx, const lc3d_plan* plan, int n_st
     c->device = device;
     HIPCHK(hipSetDevice(device));
     c->n_streams = n_streams; c->channels = plan->channels; c->ncs = n_streams * plan->channels; c->N = plan->N;
+    c->big = LC3D_LAYOUT_BIG(plan->N, plan->la);
     HIPCHK(hipMalloc((void**)&c->d_plan, sizeof(lc3d_plan)));
     HIPCHK(hipMemcpy(c->d_plan, plan, sizeof(lc3d_plan), hipMemcpyHostToDevice));
     HIPCHK(hipMalloc((void**)&c->d_chans, sizeof(lc3d_dchan) * c->ncs));
@@ -2818,7 +2822,7 @@ extern "C" int lc3hip_dec_decode(void* ctx, const void* frames, int frames_on_de
             if (c->d_ws) HIPCHK(hipFree(c->d_ws));
             c->d_rec = nullptr; c->d_ws = nullptr; c->hand_cap = 0;
             HIPCHK(hipMalloc((void**)&c->d_rec, cf * PR_WORDS * sizeof(int)));
-            HIPCHK(hipMalloc((void**)&c->d_ws, cf * WS_ROW * sizeof(float)));
+            HIPCHK(hipMalloc((void**)&c->d_ws, cf * WS_ROW(c->N) * sizeof(float)));
             c->hand_cap = cf;
         }
     }
@@ -2829,9 +2833,10 @@ extern "C" int lc3hip_dec_decode(void* ctx, const void* frames, int frames_on_de
     HIPCHK(hipEventRecord(c->ev0, s));
     /* kernel 1: one stream-frame per lane (stateless stages); kernel 2: one wave per channel-stream (stateful stages) */
     hipLaunchKernelGGL(lc3_dec_parse_kernel, dim3((unsigned)((tasks + WAVE - 1) / WAVE)), dim3(WAVE), dyn, s, c->d_plan, c->d_chans, din, in_stride, dbfi, n_frames,
-                       c->n_streams, nw_max, c->d_rec, c->d_ws);
+                       c->n_streams, nw_max, c->d_rec, c->d_ws, WS_ROW(c->N));
     HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(lc3_decode_kernel, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, c->d_rec, c->d_ws, n_frames, dpcm, bps, c->ncs, dst, dtr);
+    if (c->big) hipLaunchKernelGGL(lc3_decode_kernel_big, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, c->d_rec, c->d_ws, n_frames, dpcm, bps, c->ncs, dst, dtr);
+    else hipLaunchKernelGGL(lc3_decode_kernel, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, c->d_rec, c->d_ws, n_frames, dpcm, bps, c->ncs, dst, dtr);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev1, s));
     if (!pcm_on_device) HIPCHK(hipMemcpyAsync(pcm, dpcm, pcm_bytes, hipMemcpyDeviceToHost, s));

@@ -76,17 +76,17 @@ typedef struct {                         /* per channel-stream decoder configura
 } lc3d_dchan;
 
 /* decoder state words per channel-stream */
-#define DST_IMEM   0                                   /* 300: IMDCT overlap memory */
-#define DST_QPREV  300                                 /* 480: last good spectrum (concealment) */
-#define DST_LY     780                                 /* 864: LTPF output history */
-#define DST_LX     (780 + DEC_LY)                      /* 16 : LTPF input history */
-#define DST_SCAL   (780 + DEC_LY + DEC_LX)             /* 16 scalars */
-#define DST_WORDS  (780 + DEC_LY + DEC_LX + 16)
+#define DST_IMEM   0                                   /* 600: IMDCT overlap memory (300 used by the standard layout) */
+#define DST_QPREV  600                                 /* 960: last good spectrum (concealment) */
+#define DST_LY     1560                                /* 864: LTPF output history */
+#define DST_LX     (1560 + DEC_LY)                     /* 16 : LTPF input history */
+#define DST_SCAL   (1560 + DEC_LY + DEC_LX)            /* 16 scalars */
+#define DST_WORDS  (1560 + DEC_LY + DEC_LX + 16)
 /* hand-over between the two decoder kernels (lc3_dec_parse.inc -> lc3_dec_kernels.inc), both in HBM */
 #define PR_WORDS 112                     /* per channel-frame record: isc[0..38] of the decoder (side information), [39] = bfi after parsing, [48..111] = the 64 SNS band gains */
 #define PR_GAINS 48
 #define PR_BFI 39
-#define WS_ROW 480                       /* per channel-frame spectrum row (words) */
+#define WS_ROW(N) ((N) > 480 ? 960 : 480)  /* per channel-frame spectrum row (words) */
 enum { DS_PITCH_INT = 0, DS_PITCH_FR, DS_BETA_IDX, DS_PARAM0, DS_PARAM1, DS_PARAM2, DS_GAIN /* float */, DS_NBLOST, DS_CUM_ALPHA /* float */, DS_PLC_SEED,
        DS_PREV_BFI, DS_PREVPREV_BFI };
 

@@ -18,6 +18,7 @@ CFGS = [
     ("nb8k_10", 8000, 10.0, 0, 1, [16000, 32000]), ("nb8k_2p5", 8000, 2.5, 0, 1, [64000, 96000]),
     ("hr48k_10", 48000, 10.0, 1, 1, [128000, 400000]), ("hr48k_5", 48000, 5.0, 1, 1, [160000, 320000]),
     ("hr96k_2p5", 96000, 2.5, 1, 1, [256000, 400000]),
+    ("hr96k_5", 96000, 5.0, 1, 1, [256000, 400000]), ("hr96k_10", 96000, 10.0, 1, 1, [149600, 400000]),
 ]
 T = 20
 out = {}

@@ -42,6 +42,9 @@ CASES = [
     (48000, 5.0, 1, [160000, 320000, 600000]),
     (48000, 2.5, 1, [172800, 256000, 400000]),
     (96000, 2.5, 1, [256000, 198400, 320000, 672000]),
+    # the large-layout kernel: N = 960, or an IMDCT memory of 360 samples
+    (96000, 5.0, 1, [256000, 400000, 600000]),
+    (96000, 10.0, 1, [149600, 256000, 400000, 500000]),
 ]
 
 
