@@ -2827,13 +2827,16 @@ extern "C" int lc3hip_dec_decode(void* ctx, const void* frames, int frames_on_de
         }
     }
     const int nw_max = c->max_nbytes > 0 ? (c->max_nbytes + 3) / 4 : 1;
-    const size_t dyn = (size_t)nw_max * WAVE * sizeof(unsigned);
-    if (dyn + sizeof(ParseLds) > 64 * 1024) { fprintf(stderr, "lc3plus_hip: frame of %d bytes exceeds the parse kernel's LDS staging\n", c->max_nbytes); return 1; }
-    const long long tasks = (long long)c->n_streams * n_frames;
+    const int nlw = (WS_ROW(c->N) / 2 + 31) / 32;                          /* >= (ylen / 2 + 31) / 32 of the plan */
+    const size_t per_wave = (size_t)(nw_max + nlw) * WAVE * sizeof(unsigned);
+    int wpg = (int)((64 * 1024 - sizeof(ParseLds)) / per_wave);            /* waves per workgroup: they share the model tables */
+    if (wpg > 4) wpg = 4;
+    if (wpg < 1) { fprintf(stderr, "lc3plus_hip: frame of %d bytes exceeds the parse kernel's LDS staging\n", c->max_nbytes); return 1; }
+    const long long tasks = (long long)c->n_streams * n_frames, per_wg = (long long)wpg * WAVE;
     HIPCHK(hipEventRecord(c->ev0, s));
     /* kernel 1: one stream-frame per lane (stateless stages); kernel 2: one wave per channel-stream (stateful stages) */
-    hipLaunchKernelGGL(lc3_dec_parse_kernel, dim3((unsigned)((tasks + WAVE - 1) / WAVE)), dim3(WAVE), dyn, s, c->d_plan, c->d_chans, din, in_stride, dbfi, n_frames,
-                       c->n_streams, nw_max, c->d_rec, c->d_ws, WS_ROW(c->N));
+    hipLaunchKernelGGL(lc3_dec_parse_kernel, dim3((unsigned)((tasks + per_wg - 1) / per_wg)), dim3(wpg * WAVE), per_wave * wpg, s, c->d_plan, c->d_chans, din, in_stride,
+                       dbfi, n_frames, c->n_streams, nw_max, c->d_rec, c->d_ws, WS_ROW(c->N));
     HIPCHK(hipGetLastError());
     if (c->big) hipLaunchKernelGGL(lc3_decode_kernel_big, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, c->d_rec, c->d_ws, n_frames, dpcm, bps, c->ncs, dst, dtr);
     else hipLaunchKernelGGL(lc3_decode_kernel, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, c->d_rec, c->d_ws, n_frames, dpcm, bps, c->ncs, dst, dtr);
