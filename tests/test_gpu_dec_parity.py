@@ -243,3 +243,14 @@ def test_cli_decoder_front_end(tmp_path, fs, ms, channels, bps, bitrate, g192):
         tol = np.maximum(1, np.abs(a) >> 22)
         assert (np.abs(a - b) <= tol).all()
         assert (a == b).mean() > 0.999
+
+
+def test_soak_every_operating_point():
+    """All 24 (sample rate, frame length, mode) families x 2 seeds, mono and stereo, 16/24/32-bit output, lost and corrupt frames,
+    two launches per stream, against the oracle decoder (tools/dec_soak.py; the full-size run is quoted in DESIGN.md)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("dec_soak", os.path.join(root, "tools", "dec_soak.py"))
+    soak = importlib.util.module_from_spec(spec); spec.loader.exec_module(soak)
+    tot, bad = soak.run(2, 12, 30, verbose=False)
+    assert tot > 24 * 2 * 12 * 30 and bad == 0, (tot, bad)
