@@ -2600,7 +2600,7 @@ KERNEL_NAME(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans
 /* ------------------------------------------------------------------------------------------------ */
 /* C-ABI device shim (lc3_shim.h): context, uploads, launch                                          */
 /* ------------------------------------------------------------------------------------------------ */
-#include "lc3_dec_kernels.inc"     /* lc3_decode_kernel, or lc3_decode_kernel_big in the large-layout object */
+#include "lc3_dec_kernels.inc"     /* lc3_dec_{plc,imdct,synth}_kernel, or the _big imdct / synth kernels in the large-layout object */
 #ifndef LC3_BIG                 /* the large-layout object holds only its kernels */
 #include "lc3_dec_parse.inc"
 extern "C" __global__ void lc3_encode_kernel_big(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans, float* __restrict__ state,
@@ -2729,15 +2729,17 @@ extern "C" int lc3hip_destroy(void* ctx)
     return 0;
 }
 /* ---- decoder shim ---- */
-extern "C" __global__ void lc3_decode_kernel_big(const lc3d_plan* __restrict__ P, const lc3d_dchan* __restrict__ chans, float* __restrict__ state,
-                                                 const int* __restrict__ rec, const float* __restrict__ ws, int T, void* __restrict__ pcm, int bps, int ncs,
-                                                 uint8_t* __restrict__ status, lc3d_dec_trace* __restrict__ trace);
+extern "C" __global__ void lc3_dec_imdct_kernel_big(const lc3d_plan* __restrict__ P, const float* __restrict__ state, const int* __restrict__ rec, const float* __restrict__ ws,
+                                                    int T, int ncs, float* __restrict__ ov, lc3d_dec_trace* __restrict__ trace);
+extern "C" __global__ void lc3_dec_synth_kernel_big(const lc3d_plan* __restrict__ P, const lc3d_dchan* __restrict__ chans, float* __restrict__ state, const int* __restrict__ rec,
+                                                    const float* __restrict__ ws, const float* __restrict__ ov, int T, void* __restrict__ pcm, int bps, int ncs,
+                                                    uint8_t* __restrict__ status, lc3d_dec_trace* __restrict__ trace);
 struct lc3hip_dctx {
     int device, ncs, n_streams, channels, N, big;
     lc3d_plan* d_plan; lc3d_dchan* d_chans; float* d_state;
     uint8_t* d_in; size_t in_cap; void* d_pcm; size_t pcm_cap; uint8_t* d_bfi; size_t bfi_cap;
     lc3d_dec_trace* d_trace; size_t trace_cap; uint8_t* d_status; size_t status_cap;
-    int* d_rec; float* d_ws; size_t hand_cap; int max_nbytes;
+    int* d_rec; float* d_ws; float* d_ov; size_t hand_cap; int max_nbytes;
     hipStream_t stream; hipEvent_t ev0, ev1; float last_ms;
 };
 extern "C" int lc3hip_dec_create(void** out_ctx, const lc3d_plan* plan, int n_streams, int device)
@@ -2820,9 +2822,11 @@ extern "C" int lc3hip_dec_decode(void* ctx, const void* frames, int frames_on_de
         if (c->hand_cap < cf) {
             if (c->d_rec) HIPCHK(hipFree(c->d_rec));
             if (c->d_ws) HIPCHK(hipFree(c->d_ws));
-            c->d_rec = nullptr; c->d_ws = nullptr; c->hand_cap = 0;
+            if (c->d_ov) HIPCHK(hipFree(c->d_ov));
+            c->d_rec = nullptr; c->d_ws = nullptr; c->d_ov = nullptr; c->hand_cap = 0;
             HIPCHK(hipMalloc((void**)&c->d_rec, cf * PR_WORDS * sizeof(int)));
             HIPCHK(hipMalloc((void**)&c->d_ws, cf * WS_ROW(c->N) * sizeof(float)));
+            HIPCHK(hipMalloc((void**)&c->d_ov, cf * (c->big ? OV_ROW_BIG : OV_ROW_STD) * sizeof(float)));
             c->hand_cap = cf;
         }
     }
@@ -2834,12 +2838,21 @@ extern "C" int lc3hip_dec_decode(void* ctx, const void* frames, int frames_on_de
     if (wpg < 1) { fprintf(stderr, "lc3plus_hip: frame of %d bytes exceeds the parse kernel's LDS staging\n", c->max_nbytes); return 1; }
     const long long tasks = (long long)c->n_streams * n_frames, per_wg = (long long)wpg * WAVE;
     HIPCHK(hipEventRecord(c->ev0, s));
-    /* kernel 1: one stream-frame per lane (stateless stages); kernel 2: one wave per channel-stream (stateful stages) */
+    /* parse: one stream-frame per lane; concealment bookkeeping: one channel-stream per lane; IMDCT: one channel-frame per wave;
+     * synthesis: one channel-stream per wave (lc3_dec_kernels.inc) */
     hipLaunchKernelGGL(lc3_dec_parse_kernel, dim3((unsigned)((tasks + per_wg - 1) / per_wg)), dim3(wpg * WAVE), per_wave * wpg, s, c->d_plan, c->d_chans, din, in_stride,
                        dbfi, n_frames, c->n_streams, nw_max, c->d_rec, c->d_ws, WS_ROW(c->N));
     HIPCHK(hipGetLastError());
-    if (c->big) hipLaunchKernelGGL(lc3_decode_kernel_big, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, c->d_rec, c->d_ws, n_frames, dpcm, bps, c->ncs, dst, dtr);
-    else hipLaunchKernelGGL(lc3_decode_kernel, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, c->d_rec, c->d_ws, n_frames, dpcm, bps, c->ncs, dst, dtr);
+    hipLaunchKernelGGL(lc3_dec_plc_kernel, dim3((unsigned)((c->ncs + WAVE - 1) / WAVE)), dim3(WAVE), 0, s, c->d_plan, c->d_state, c->d_rec, n_frames, c->ncs);
+    HIPCHK(hipGetLastError());
+    const unsigned ncf = (unsigned)((size_t)c->ncs * ((n_frames + IMDCT_FPW - 1) / IMDCT_FPW));     /* runs of IMDCT_FPW frames */
+    if (c->big) {
+        hipLaunchKernelGGL(lc3_dec_imdct_kernel_big, dim3(ncf), dim3(WAVE), 0, s, c->d_plan, c->d_state, c->d_rec, c->d_ws, n_frames, c->ncs, c->d_ov, dtr);
+        hipLaunchKernelGGL(lc3_dec_synth_kernel_big, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, c->d_rec, c->d_ws, c->d_ov, n_frames, dpcm, bps, c->ncs, dst, dtr);
+    } else {
+        hipLaunchKernelGGL(lc3_dec_imdct_kernel, dim3(ncf), dim3(WAVE), 0, s, c->d_plan, c->d_state, c->d_rec, c->d_ws, n_frames, c->ncs, c->d_ov, dtr);
+        hipLaunchKernelGGL(lc3_dec_synth_kernel, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, c->d_rec, c->d_ws, c->d_ov, n_frames, dpcm, bps, c->ncs, dst, dtr);
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev1, s));
     if (!pcm_on_device) HIPCHK(hipMemcpyAsync(pcm, dpcm, pcm_bytes, hipMemcpyDeviceToHost, s));
@@ -2857,7 +2870,7 @@ extern "C" int lc3hip_dec_destroy(void* ctx)
     lc3hip_dctx* c = (lc3hip_dctx*)ctx;
     if (!c) return 0;
     hipSetDevice(c->device);
-    hipFree(c->d_plan); hipFree(c->d_chans); hipFree(c->d_state); hipFree(c->d_in); hipFree(c->d_pcm); hipFree(c->d_bfi); hipFree(c->d_trace); hipFree(c->d_status); hipFree(c->d_rec); hipFree(c->d_ws);
+    hipFree(c->d_plan); hipFree(c->d_chans); hipFree(c->d_state); hipFree(c->d_in); hipFree(c->d_pcm); hipFree(c->d_bfi); hipFree(c->d_trace); hipFree(c->d_status); hipFree(c->d_rec); hipFree(c->d_ws); hipFree(c->d_ov);
     hipStreamDestroy(c->stream); hipEventDestroy(c->ev0); hipEventDestroy(c->ev1);
     free(c);
     return 0;

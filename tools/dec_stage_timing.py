@@ -7,8 +7,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import audio_codec_amd.api as api
 api.lib_path = lambda: os.path.join(ROOT, "audio_codec_amd", "liblc3plus_hip_timing.so")
 from lc3_harness import synth_pcm
-NAMES = ["load + side info", "range decoder + residual bits", "sns decode", "residual + noise filling", "global gain", "tns lattice",
-         "sns shaping", "concealment / memory", "imdct", "ltpf", "output"]
+NAMES = ["hand-over + overlap-add", "-", "-", "-", "-", "-", "-", "-", "-", "ltpf", "output"]   # stamps of lc3_dec_synth_kernel
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 T = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 br = int(sys.argv[3]) if len(sys.argv) > 3 else 64000
