@@ -8,8 +8,7 @@
  * no CPU fallback: if no MI355X / HIP runtime is available the first lc3_enc_* call that needs the device
  * returns LC3_ERROR and prints a diagnostic.
  *
- * The float decoder (lc3_dec_*, R/lc3.h:318-406) is exported too; it runs in the standard kernel layout
- * (frame length <= 480 samples and MDCT memory <= 300: every operating point except 96 kHz at 5 and 10 ms).
+ * The float decoder (lc3_dec_*, R/lc3.h:318-406) is exported too, for every operating point of the reference.
  * Error protection (lc3_*_set_ep_*) is not part of the float reference build and has no entry points.
  */
 #ifndef LC3PLUS_HIP_LC3_H
