@@ -95,6 +95,33 @@ def _cpu_worker(args):
     return time.time() - t0
 
 
+def cpu_baseline_decode(frames, nbytes, n_streams, T):
+    """Reference (or restated) DECODER on the host cores over a bounded sample of the bench bitstreams (rank 0, --workload d*)."""
+    from concurrent.futures import ProcessPoolExecutor
+    cores = max(1, min(os.cpu_count() or 1, 32))
+    per = max(1, n_streams // cores)
+    kind = "reference" if os.path.exists(os.path.join(ROOT, "oracle", "_ref", "liblc3_etsi_fl.so")) else "port"
+    t0 = time.time()
+    with ProcessPoolExecutor(max_workers=cores) as ex:
+        secs = list(ex.map(_cpu_dec_worker, [(kind, frames[i * per:(i + 1) * per, :T], nbytes[i * per:(i + 1) * per]) for i in range(cores)]))
+    wall = time.time() - t0
+    return {"value": round(per * T * cores / max(secs) / 1e6, 6), "unit": "Mframes/s", "cores": cores, "kind": kind,
+            "sample": "%d streams x %d frames of the bench bitstreams, %d worker processes, %.1f s wall incl. start-up; slowest worker %.2f s of decode"
+                      % (per * cores, T, cores, wall, max(secs))}
+
+
+def _cpu_dec_worker(args):
+    kind, frames, nbytes = args
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import lc3_harness as H
+    t0 = time.time()
+    for s in range(frames.shape[0]):
+        dec = H.RefDecoder(FS, 1, FRAME_MS, 0) if kind == "reference" else H.OracleDecoder(FS, 1, FRAME_MS, 0)
+        for t in range(frames.shape[1]):
+            dec.decode(frames[s, t, :nbytes[s]], 0, 16)
+    return time.time() - t0
+
+
 def other_workload(a):
     """Single-GPU record runs of the other BASELINE configs (same timing protocol; no CPU baseline; informational)."""
     import torch
@@ -130,12 +157,18 @@ def other_workload(a):
     nbytes = [batch.num_bytes(i) for i in range(min(B, len(rates)))]
     algo = B * T * (2 * n * ch) + T * sum(batch.num_bytes(i) for i in range(B))
     kern_ms = e0.elapsed_time(e1) / a.steps
-    print(json.dumps({"metric": "Mframes/s %s (channel-frames)" % what, "value": round(B * T * ch * a.steps / wall / 1e6, 4), "unit": "Mframes/s",
+    extra = {}
+    if a.workload.startswith("d") and not a.no_cpu_baseline:
+        nbl = [batch.num_bytes(i) for i in range(B)]
+        extra["cpu_baseline"] = cpu_baseline_decode(out[:2048].cpu().numpy(), nbl[:2048], min(B, 2048), min(T, 64))
+    line = {"metric": "Mframes/s %s (channel-frames)" % what, "value": round(B * T * ch * a.steps / wall / 1e6, 4), "unit": "Mframes/s",
                       "n_gpus": 1, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(wall / a.steps * 1e3, 4), "higher_is_better": True,
                       "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                       "config": {"workload": "%s: %d streams x %d frames, %d Hz / %.1f ms%s, %d ch, bytes/frame %s" % (a.workload, B, T, fs, ms, " hr" if hr else "", ch, nbytes)},
                       "roofline": {"bound": "hbm", "achieved": round(algo / (kern_ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": round(algo / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None, "kernel_ms_avg": round(kern_ms, 4)}}))
+                                   "frac": round(algo / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": measured_traffic(a.workload, B, T), "kernel_ms_avg": round(kern_ms, 4)}}
+    line.update(extra)
+    print(json.dumps(line))
 
 
 def measured_traffic(workload, B, T):
@@ -144,8 +177,9 @@ def measured_traffic(workload, B, T):
     try:
         with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
             t = json.load(f)
-        if t["workload"] == workload and t["streams"] == B and t["frames"] == T:
-            return int(t["traffic_bytes"])
+        for e in [t] + list(t.get("more", [])):
+            if e["workload"] == workload and e["streams"] == B and e["frames"] == T:
+                return int(e["traffic_bytes"])
     except (OSError, KeyError, ValueError):
         pass
     return None
