@@ -2830,7 +2830,8 @@ extern "C" int lc3hip_dec_decode(void* ctx, const void* frames, int frames_on_de
             c->hand_cap = cf;
         }
     }
-    const int nw_max = c->max_nbytes > 0 ? (c->max_nbytes + 3) / 4 : 1;
+    /* frames of up to 128 bytes are staged in LDS; larger ones would cut the waves per workgroup and are read from global memory */
+    const int nw_max = c->max_nbytes > 128 ? 0 : c->max_nbytes > 0 ? (c->max_nbytes + 3) / 4 : 1;
     const int nlw = (WS_ROW(c->N) / 2 + 31) / 32;                          /* >= (ylen / 2 + 31) / 32 of the plan */
     const size_t per_wave = (size_t)(nw_max + nlw) * WAVE * sizeof(unsigned);
     int wpg = (int)((64 * 1024 - sizeof(ParseLds)) / per_wave);            /* waves per workgroup: they share the model tables */
@@ -2840,8 +2841,10 @@ extern "C" int lc3hip_dec_decode(void* ctx, const void* frames, int frames_on_de
     HIPCHK(hipEventRecord(c->ev0, s));
     /* parse: one stream-frame per lane; concealment bookkeeping: one channel-stream per lane; IMDCT: one channel-frame per wave;
      * synthesis: one channel-stream per wave (lc3_dec_kernels.inc) */
-    hipLaunchKernelGGL(lc3_dec_parse_kernel, dim3((unsigned)((tasks + per_wg - 1) / per_wg)), dim3(wpg * WAVE), per_wave * wpg, s, c->d_plan, c->d_chans, din, in_stride,
-                       dbfi, n_frames, c->n_streams, nw_max, c->d_rec, c->d_ws, WS_ROW(c->N));
+    if (nw_max) hipLaunchKernelGGL(lc3_dec_parse_kernel, dim3((unsigned)((tasks + per_wg - 1) / per_wg)), dim3(wpg * WAVE), per_wave * wpg, s, c->d_plan, c->d_chans, din, in_stride,
+                                   dbfi, n_frames, c->n_streams, nw_max, c->d_rec, c->d_ws, WS_ROW(c->N));
+    else hipLaunchKernelGGL(lc3_dec_parse_kernel_g, dim3((unsigned)((tasks + per_wg - 1) / per_wg)), dim3(wpg * WAVE), per_wave * wpg, s, c->d_plan, c->d_chans, din, in_stride,
+                            dbfi, n_frames, c->n_streams, nw_max, c->d_rec, c->d_ws, WS_ROW(c->N));
     HIPCHK(hipGetLastError());
     hipLaunchKernelGGL(lc3_dec_plc_kernel, dim3((unsigned)((c->ncs + WAVE - 1) / WAVE)), dim3(WAVE), 0, s, c->d_plan, c->d_state, c->d_rec, n_frames, c->ncs);
     HIPCHK(hipGetLastError());
