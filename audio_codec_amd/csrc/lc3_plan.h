@@ -86,8 +86,8 @@ typedef struct {                         /* per channel-stream decoder configura
 #define PR_WORDS 112                     /* per channel-frame record: isc[0..38] of the decoder (side information), [39] = bfi after parsing, [48..111] = the 64 SNS band gains */
 #define PR_GAINS 48
 #define PR_PLC 40                        /* lost frames: [40] nbLostCmpt, [41] cumulative attenuation (float), [42] first seed, [43] last good frame of the launch or -1 */
-#define OV_ROW_STD 784                    /* windowed frame in HBM: [N samples before the overlap-add | N - la_zeros memory samples], standard layout (480 + 300) */
-#define OV_ROW_BIG 1568                   /* large layout (960 + 600) */
+#define OV_ROW_STD 480                    /* transformed frame in HBM: the N samples of the time-domain aliasing buffer (R/imdct.c:34-44), standard layout */
+#define OV_ROW_BIG 960                    /* large layout */
 #define PR_BFI 39
 #define WS_ROW(N) ((N) > 480 ? 960 : 480)  /* per channel-frame spectrum row (words) */
 enum { DS_PITCH_INT = 0, DS_PITCH_FR, DS_BETA_IDX, DS_PARAM0, DS_PARAM1, DS_PARAM2, DS_GAIN /* float */, DS_NBLOST, DS_CUM_ALPHA /* float */, DS_PLC_SEED,
