@@ -2437,7 +2437,7 @@ STAGE void st_bitstream(const lc3d_plan* __restrict__ P, const lc3d_chan* __rest
 extern "C" __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(KERNEL_WAVES, KERNEL_WAVES)))
 KERNEL_NAME(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans, float* __restrict__ state,
                   const void* __restrict__ pcm, int bitdepth, int T, uint8_t* __restrict__ out, int out_stride, int ncs,
-                  lc3d_trace* __restrict__ trace)
+                  lc3d_trace* __restrict__ trace, int* __restrict__ dump /* [cs][T][dstride] hand-over to lc3_enc_pack_kernel, or null: write the bytes here */, int dstride)
 {
     __shared__ WaveLds L;
     const int lane = threadIdx.x;
@@ -2573,6 +2573,21 @@ KERNEL_NAME(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans
         if (uni(L.isc[I_LSB]) == 0) st_residual(P, L, lane, tbq, uni(L.isc[I_NBITS2]));
         else { for (int i = lane; i < 160; i += WAVE) ((uint32_t*)RESB(L))[i] = 0; if (lane == 0) L.isc[I_NRES] = 0; LSYNC(); }
         TICK(15);
+        if (dump) {
+            /* the bitstream of a frame depends on nothing but this: scalars, residual bits, quantised lines up to lastnz.  The
+             * serial writer runs one frame per lane in lc3_enc_pack_kernel. */
+            int* r = dump + ((size_t)cs * T + t) * dstride;
+            if (lane < 56) r[lane] = L.isc[lane];
+            const int lastnz = uni(L.isc[I_LASTNZ]), nresw = uni(L.isc[I_LSB]) == 0 ? (uni(L.isc[I_NRES]) + 31) >> 5 : 0;
+            for (int i = lane; i < nresw; i += WAVE) r[PK_RES + i] = (int)((const uint32_t*)RESB(L))[i];
+            const int* xq = XQ(L);
+            if (PI(hrmode)) { for (int i = lane; i < ((lastnz + 1) & ~1); i += WAVE) r[PK_XQ + i] = xq[i]; }
+            else for (int p = lane; p < ((lastnz + 1) >> 1); p += WAVE) r[PK_XQ + p] = (xq[2 * p] & 0xFFFF) | (xq[2 * p + 1] << 16);
+            LSYNC();
+            TICK(16);
+            TICK(17);
+            continue;
+        }
         st_bitstream(P, C, L, lane);
         LSYNC();
         TICK(16);
@@ -2605,12 +2620,14 @@ KERNEL_NAME(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans
 #include "lc3_dec_parse.inc"
 extern "C" __global__ void lc3_encode_kernel_big(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans, float* __restrict__ state,
                                                  const void* __restrict__ pcm, int bitdepth, int T, uint8_t* __restrict__ out, int out_stride, int ncs,
-                                                 lc3d_trace* __restrict__ trace);
+                                                 lc3d_trace* __restrict__ trace, int* __restrict__ dump, int dstride);
+#include "lc3_enc_pack.inc"
 struct lc3hip_ctx {
     int device, ncs, n_streams, channels, N, big, state_words;
     lc3d_plan* d_plan; lc3d_chan* d_chans; float* d_state;
     void* d_pcm; size_t pcm_cap; uint8_t* d_out; size_t out_cap;
     lc3d_trace* d_trace; size_t trace_cap;
+    int* d_dump; size_t dump_cap; int hr, max_nbytes, fused;
     hipStream_t stream; hipEvent_t ev0, ev1; float last_ms;
 };
 
@@ -2627,6 +2644,8 @@ extern "C" int lc3hip_create(void** out_ctx, const lc3d_plan* plan, int n_stream
     HIPCHK(hipSetDevice(device));
     c->n_streams = n_streams; c->channels = plan->channels; c->ncs = n_streams * plan->channels; c->N = plan->N;
     c->big = LC3D_LAYOUT_BIG(plan->N, plan->la);
+    c->hr = plan->hrmode;
+    { const char* e = getenv("LC3PLUS_ENC_FUSED"); c->fused = e && e[0] == '1'; }     /* diagnostic: the bitstream writer inside lc3_encode_kernel */
     c->state_words = LC3D_STATE_WORDS(c->big ? LC3D_MEMCAP_BIG : LC3D_MEMCAP_STD);
     HIPCHK(hipMalloc((void**)&c->d_plan, sizeof(lc3d_plan)));
     HIPCHK(hipMemcpy(c->d_plan, plan, sizeof(lc3d_plan), hipMemcpyHostToDevice));
@@ -2657,6 +2676,7 @@ extern "C" int lc3hip_upload_chans(void* ctx, const lc3d_chan* chans, int first,
     lc3hip_ctx* c = (lc3hip_ctx*)ctx;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpy(c->d_chans + first, chans, sizeof(lc3d_chan) * count, hipMemcpyHostToDevice));
+    for (int i = 0; i < count; i++) if (chans[i].nbytes > c->max_nbytes) c->max_nbytes = chans[i].nbytes;
     return 0;
 }
 
@@ -2687,11 +2707,34 @@ extern "C" int lc3hip_encode(void* ctx, const void* pcm, int pcm_on_device, int 
         HIPCHK(hipMemsetAsync(c->d_trace, 0, tb, s));
         dtr = c->d_trace;
     }
+    /* two kernels: lc3_encode_kernel (one wave per channel-stream, frames in order) leaves each frame's parameters and quantised
+     * spectrum in a record; lc3_enc_pack_kernel (one channel-frame per lane) writes the bytes.  With stage traces, or with
+     * LC3PLUS_ENC_FUSED=1, the first kernel writes the bytes itself. */
+    int* ddump = nullptr; int dstride = 0;
+    /* frames above 128 bytes would leave the pack kernel one wave per SIMD (its LDS staging is sized by the largest frame of the
+     * batch): such batches keep the single-kernel path */
+    if (!trace_host && !c->fused && c->max_nbytes <= 128) {
+        dstride = PK_STRIDE(c->N, c->hr);
+        const size_t need = (size_t)c->ncs * n_frames * dstride;
+        if (c->dump_cap < need) { if (c->d_dump) HIPCHK(hipFree(c->d_dump)); c->d_dump = nullptr; c->dump_cap = 0; HIPCHK(hipMalloc((void**)&c->d_dump, need * sizeof(int))); c->dump_cap = need; }
+        ddump = c->d_dump;
+    }
     HIPCHK(hipEventRecord(c->ev0, s));
     if (c->big) hipLaunchKernelGGL(lc3_encode_kernel_big, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames,
-                                   dout, out_stride, c->ncs, dtr);
+                                   dout, out_stride, c->ncs, dtr, ddump, dstride);
     else hipLaunchKernelGGL(lc3_encode_kernel, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames,
-                            dout, out_stride, c->ncs, dtr);
+                            dout, out_stride, c->ncs, dtr, ddump, dstride);
+    if (ddump) {
+        HIPCHK(hipGetLastError());
+        const int nw_max = c->max_nbytes > 0 ? (c->max_nbytes + 3) / 4 : 1;
+        const size_t per_wave = (size_t)nw_max * WAVE * sizeof(unsigned);
+        int wpg = (int)((64 * 1024 - sizeof(PackLds)) / per_wave);
+        if (wpg > 4) wpg = 4;
+        if (wpg < 1) { fprintf(stderr, "lc3plus_hip: frame of %d bytes exceeds the pack kernel's LDS staging\n", c->max_nbytes); return 1; }
+        const long long tasks = (long long)c->ncs * n_frames, per_wg = (long long)wpg * WAVE;
+        hipLaunchKernelGGL(lc3_enc_pack_kernel, dim3((unsigned)((tasks + per_wg - 1) / per_wg)), dim3(wpg * WAVE), per_wave * wpg, s, c->d_plan, c->d_chans, ddump, dstride,
+                           n_frames, c->ncs, nw_max, dout, out_stride);
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev1, s));
     if (!out_on_device) HIPCHK(hipMemcpyAsync(out, dout, out_bytes, hipMemcpyDeviceToHost, s));
@@ -2722,6 +2765,7 @@ extern "C" int lc3hip_destroy(void* ctx)
     if (c->d_state) hipFree(c->d_state);
     if (c->d_pcm) hipFree(c->d_pcm);
     if (c->d_out) hipFree(c->d_out);
+    if (c->d_dump) hipFree(c->d_dump);
     if (c->d_trace) hipFree(c->d_trace);
     hipEventDestroy(c->ev0); hipEventDestroy(c->ev1);
     hipStreamDestroy(c->stream);

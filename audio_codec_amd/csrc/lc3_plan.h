@@ -82,6 +82,10 @@ typedef struct {                         /* per channel-stream decoder configura
 #define DST_LX     (1560 + DEC_LY)                     /* 16 : LTPF input history */
 #define DST_SCAL   (1560 + DEC_LY + DEC_LX)            /* 16 scalars */
 #define DST_WORDS  (1560 + DEC_LY + DEC_LX + 16)
+/* hand-over between the two encoder kernels (lc3_encode_kernel -> lc3_enc_pack_kernel, lc3_enc_pack.inc), per channel-frame in HBM */
+#define PK_RES 64                        /* [0..55] the encoder's isc[] scalars; [64..223] residual bits, LSB first (the LSB-mode list in LSB mode) */
+#define PK_XQ  224                       /* quantised spectrum up to lastnz: one word per 2-tuple (int16 pairs), or int32 lines in high-resolution mode */
+#define PK_STRIDE(N, hr) (PK_XQ + ((hr) ? ((N) > 480 ? 960 : 480) : ((N) > 480 ? 480 : 240)))
 /* hand-over between the two decoder kernels (lc3_dec_parse.inc -> lc3_dec_kernels.inc), both in HBM */
 #define PR_WORDS 112                     /* per channel-frame record: isc[0..38] of the decoder (side information), [39] = bfi after parsing, [48..111] = the 64 SNS band gains */
 #define PR_GAINS 48
