@@ -21,9 +21,10 @@ import csv, glob, collections
 acc = collections.defaultdict(list)
 for f in glob.glob("$OUT/pmc_*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "lc3_encode" in r["Kernel_Name"]: acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        k = r["Kernel_Name"].split("(")[0]
+        if k.startswith("lc3_enc"): acc[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
 with open("$OUT/pmc_summary.txt", "w") as o:
-    for k in sorted(acc): o.write("%s %.0f (mean of %d launches)\n" % (k, sum(acc[k]) / len(acc[k]), len(acc[k])))
+    for k in sorted(acc): o.write("%s %s %.0f (mean of %d launches)\n" % (k[0], k[1], sum(acc[k]) / len(acc[k]), len(acc[k])))
 print(open("$OUT/pmc_summary.txt").read())
 PY
 head -3 $OUT/stats/*kernel_stats.csv | cut -c1-200
