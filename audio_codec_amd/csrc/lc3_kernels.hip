@@ -2727,7 +2727,7 @@ extern "C" int lc3hip_encode(void* ctx, const void* pcm, int pcm_on_device, int 
     if (ddump) {
         HIPCHK(hipGetLastError());
         const int nw_max = c->max_nbytes > 0 ? (c->max_nbytes + 3) / 4 : 1;
-        const size_t per_wave = (size_t)nw_max * WAVE * sizeof(unsigned);
+        const size_t per_wave = (size_t)(nw_max + PK_XBUF) * WAVE * sizeof(unsigned);
         int wpg = (int)((64 * 1024 - sizeof(PackLds)) / per_wave);
         if (wpg > 4) wpg = 4;
         if (wpg < 1) { fprintf(stderr, "lc3plus_hip: frame of %d bytes exceeds the pack kernel's LDS staging\n", c->max_nbytes); return 1; }
