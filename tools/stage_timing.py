@@ -1,4 +1,5 @@
-"""Diagnostic: per-stage wave latency (shader cycles per frame) from the -DLC3_STAGE_TIMING build.
+"""Diagnostic: per-stage wave latency (shader cycles per frame) of lc3_encode_kernel from the -DLC3_STAGE_TIMING build.
+The stamps are collected through the traced entry point, i.e. in the single-kernel path (bitstream stage included).
 Usage (GPU box): python tools/stage_timing.py [B T bitrate]"""
 import ctypes as C, os, sys
 import numpy as np
