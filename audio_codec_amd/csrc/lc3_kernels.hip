@@ -363,12 +363,17 @@ __device__ __forceinline__ double rl_d(double v, int l)
 /* ------------------------------------------------------------------------------------------------ */
 
 /* ---- 12.8 kHz resampler + 50 Hz high-pass: R/resamp12k8.c:13-84.  Appends len12 samples to h12. ---- */
-STAGE void st_resample(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
+STAGE void st_resample(const lc3d_plan* __restrict__ P, WaveLds& L, int lane, const float* __restrict__ yin /* the frame's HP-filtered 12.8 kHz samples from the pre-kernels, or null */)
 {
     const int mlen = PI(rs_mem_in_len), stride = PI(rs_stride), n12 = PI(n12), len12 = PI(len12), N = PI(N);
     const float sf = PF(rs_scale);
     const float* buf = &L.xbuf[MEMCAP - mlen];      /* [mem_in | x] */
     SUB_BEGIN();
+    float y[2];
+    if (yin) {                                       /* lc3_enc_resample_kernel + lc3_enc_hp50_kernel (lc3_enc_pre.inc) have done the work */
+        y[0] = lane < len12 ? yin[lane] : 0.0f; y[1] = lane + 64 < len12 ? yin[lane + 64] : 0.0f;
+        (void)buf; (void)stride; (void)n12; (void)N; (void)sf;
+    } else {
     /* polyphase FIR, R/resamp12k8.c:48-57: out[n] = sum_m (buf[.]*sf) * lp[.] in the reference's tap order.  The scaled samples
      * are formed once (sm is idle here); a lane's two outputs (n = lane, lane + 64) share one phase, whose taps are held in
      * registers 10 at a time. */
@@ -431,8 +436,9 @@ STAGE void st_resample(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
         }
     }
     LSYNC();
-    float y[2];
     y[0] = lane < len12 ? yo[lane] : 0.0f; y[1] = lane + 64 < len12 ? yo[lane + 64] : 0.0f;
+    if (lane == 0) { L.fsc[F_HP0] = (float)u11; L.fsc[F_HP1] = (float)u21; }
+    }
     SUB(2);
     float keep[6];
 #pragma unroll
@@ -442,7 +448,6 @@ STAGE void st_resample(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
     for (int k = 0; k < 6; k++) { const int i = lane + 64 * k; if (i + len12 < 384) L.h12[i] = keep[k]; }
     if (lane < len12) L.h12[384 - len12 + lane] = y[0];
     if (lane + 64 < len12) L.h12[384 - len12 + 64 + lane] = y[1];
-    if (lane == 0) { L.fsc[F_HP0] = (float)u11; L.fsc[F_HP1] = (float)u21; }
     LSYNC();
     SUB(3);
 }
@@ -2437,7 +2442,8 @@ STAGE void st_bitstream(const lc3d_plan* __restrict__ P, const lc3d_chan* __rest
 extern "C" __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_per_eu(KERNEL_WAVES, KERNEL_WAVES)))
 KERNEL_NAME(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans, float* __restrict__ state,
                   const void* __restrict__ pcm, int bitdepth, int T, uint8_t* __restrict__ out, int out_stride, int ncs,
-                  lc3d_trace* __restrict__ trace, int* __restrict__ dump /* [cs][T][dstride] hand-over to lc3_enc_pack_kernel, or null: write the bytes here */, int dstride)
+                  lc3d_trace* __restrict__ trace, int* __restrict__ dump /* [cs][T][dstride] hand-over to lc3_enc_pack_kernel, or null: write the bytes here */, int dstride,
+                  const float* __restrict__ y12 /* [cs][T][128] HP-filtered 12.8 kHz signal from the pre-kernels, or null: resample here */)
 {
     __shared__ WaveLds L;
     const int lane = threadIdx.x;
@@ -2494,7 +2500,7 @@ KERNEL_NAME(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans
         LSYNC();
         TICK(0);
 
-        st_resample(P, L, lane);
+        st_resample(P, L, lane, y12 ? y12 + ((size_t)cs * T + t) * 128 : nullptr);
         TICK(2);
         if (tr) for (int i = lane; i < PI(len12) + 1; i += WAVE) tr->s12k8[i] = L.h12[384 - PI(len12) - 24 + i];
         st_olpa(P, L, lane);
@@ -2607,7 +2613,7 @@ KERNEL_NAME(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans
     for (int i = lane; i < MEMCAP; i += WAVE) stp[LC3D_ST_XPREV + i] = L.xbuf[i];
     for (int i = lane; i < 384; i += WAVE) stp[LC3D_ST_H12(MEMCAP) + i] = L.h12[i];
     for (int i = lane; i < 194; i += WAVE) stp[LC3D_ST_H6(MEMCAP) + i] = L.h6[i];
-    if (lane < 12) stp[LC3D_ST_SCAL(MEMCAP) + lane] = L.fsc[lane];
+    if (lane < 12 && !(y12 && lane < 2)) stp[LC3D_ST_SCAL(MEMCAP) + lane] = L.fsc[lane];      /* the HP50 state belongs to lc3_enc_hp50_kernel when it runs */
     if (lane < 16) ((int*)stp)[LC3D_ST_SCAL(MEMCAP) + 16 + lane] = L.isc[lane];
     (void)ml;
 }
@@ -2620,14 +2626,15 @@ KERNEL_NAME(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans
 #include "lc3_dec_parse.inc"
 extern "C" __global__ void lc3_encode_kernel_big(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans, float* __restrict__ state,
                                                  const void* __restrict__ pcm, int bitdepth, int T, uint8_t* __restrict__ out, int out_stride, int ncs,
-                                                 lc3d_trace* __restrict__ trace, int* __restrict__ dump, int dstride);
+                                                 lc3d_trace* __restrict__ trace, int* __restrict__ dump, int dstride, const float* __restrict__ y12);
 #include "lc3_enc_pack.inc"
+#include "lc3_enc_pre.inc"
 struct lc3hip_ctx {
     int device, ncs, n_streams, channels, N, big, state_words;
     lc3d_plan* d_plan; lc3d_chan* d_chans; float* d_state;
     void* d_pcm; size_t pcm_cap; uint8_t* d_out; size_t out_cap;
     lc3d_trace* d_trace; size_t trace_cap;
-    int* d_dump; size_t dump_cap; int hr, max_nbytes, fused;
+    int* d_dump; size_t dump_cap; int hr, max_nbytes, fused; float* d_y12; size_t y12_cap;
     hipStream_t stream; hipEvent_t ev0, ev1; float last_ms;
 };
 
@@ -2719,11 +2726,25 @@ extern "C" int lc3hip_encode(void* ctx, const void* pcm, int pcm_on_device, int 
         if (c->dump_cap < need) { if (c->d_dump) HIPCHK(hipFree(c->d_dump)); c->d_dump = nullptr; c->dump_cap = 0; HIPCHK(hipMalloc((void**)&c->d_dump, need * sizeof(int))); c->dump_cap = need; }
         ddump = c->d_dump;
     }
+    /* ahead of it: the 12.8 kHz resampler of all frames at once and its HP50 recurrence one stream per lane (lc3_enc_pre.inc) */
+    float* dy12 = nullptr;
+    if (!trace_host && !c->fused) {
+        const size_t need = (size_t)c->ncs * n_frames * 128;
+        if (c->y12_cap < need) { if (c->d_y12) HIPCHK(hipFree(c->d_y12)); c->d_y12 = nullptr; c->y12_cap = 0; HIPCHK(hipMalloc((void**)&c->d_y12, need * sizeof(float))); c->y12_cap = need; }
+        dy12 = c->d_y12;
+    }
     HIPCHK(hipEventRecord(c->ev0, s));
+    if (dy12) {
+        const int mc = c->big ? LC3D_MEMCAP_BIG : LC3D_MEMCAP_STD;
+        const unsigned runs = (unsigned)((n_frames + PRE_FPW - 1) / PRE_FPW);
+        hipLaunchKernelGGL(lc3_enc_resample_kernel, dim3((unsigned)c->ncs * runs), dim3(WAVE), 0, s, c->d_plan, c->d_state, c->state_words, mc, dpcm, bitdepth, n_frames, c->ncs, dy12);
+        hipLaunchKernelGGL(lc3_enc_hp50_kernel, dim3((unsigned)((c->ncs + WAVE - 1) / WAVE)), dim3(WAVE), 0, s, c->d_plan, c->d_state, c->state_words, LC3D_ST_SCAL(mc), n_frames, c->ncs, dy12);
+        HIPCHK(hipGetLastError());
+    }
     if (c->big) hipLaunchKernelGGL(lc3_encode_kernel_big, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames,
-                                   dout, out_stride, c->ncs, dtr, ddump, dstride);
+                                   dout, out_stride, c->ncs, dtr, ddump, dstride, dy12);
     else hipLaunchKernelGGL(lc3_encode_kernel, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames,
-                            dout, out_stride, c->ncs, dtr, ddump, dstride);
+                            dout, out_stride, c->ncs, dtr, ddump, dstride, dy12);
     if (ddump) {
         HIPCHK(hipGetLastError());
         const int nw_max = c->max_nbytes > 0 ? (c->max_nbytes + 3) / 4 : 1;
@@ -2766,6 +2787,7 @@ extern "C" int lc3hip_destroy(void* ctx)
     if (c->d_pcm) hipFree(c->d_pcm);
     if (c->d_out) hipFree(c->d_out);
     if (c->d_dump) hipFree(c->d_dump);
+    if (c->d_y12) hipFree(c->d_y12);
     if (c->d_trace) hipFree(c->d_trace);
     hipEventDestroy(c->ev0); hipEventDestroy(c->ev1);
     hipStreamDestroy(c->stream);
