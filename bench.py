@@ -261,7 +261,7 @@ def main():
                        "streams_per_gpu": B, "frames_per_step": T, "parallelism": "streams sharded over %d GPU(s), no collectives" % world},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": measured_traffic(a.workload, B, T),
-                         "kernel": "lc3_encode_kernel + lc3_enc_pack_kernel (one encode() call = the two launches; HIP events around both)", "kernel_ms_avg": round(kern_ms, 4),
+                         "kernel": "lc3_enc_resample_kernel + lc3_enc_hp50_kernel + lc3_encode_kernel + lc3_enc_pack_kernel (one encode() call = these four launches; HIP events around all of them)", "kernel_ms_avg": round(kern_ms, 4),
                          "algorithmic_bytes_per_launch": B * T * ALGO_BYTES_PER_FRAME,
                          "note": "serial-chain (instruction-issue) bound, not HBM bound: see DESIGN.md"},
         }
