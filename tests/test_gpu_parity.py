@@ -271,7 +271,7 @@ def test_large_sweep_vs_oracle(fs, ms, hr, N, B, T, rates):
 
 def test_soak_every_operating_point():
     """All 24 (sample rate, frame length, mode) families of the reference x 2 seeds x 32 streams x 36 frames against the oracle
-    (tools/soak.py; the full-size run, 1.5 M frames, is quoted in DESIGN.md)."""
+    (tools/soak.py; the full-size run, 3.1 M frames, is quoted in DESIGN.md)."""
     import importlib.util
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     spec = importlib.util.spec_from_file_location("soak", os.path.join(root, "tools", "soak.py"))
