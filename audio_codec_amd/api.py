@@ -18,7 +18,7 @@ EXPORTS = [
     "lc3_enc_fl", "lc3_enc16", "lc3_enc24", "lc3_enc32", "lc3_enc_free_memory", "lc3_free_encoder_structs",
     "lc3plus_enc_batch_create", "lc3plus_enc_batch_destroy", "lc3plus_enc_batch_input_samples",
     "lc3plus_enc_batch_num_bytes", "lc3plus_enc_batch_stride", "lc3plus_enc_batch_set_bitrate",
-    "lc3plus_enc_batch_set_bandwidth", "lc3plus_enc_batch_encode", "lc3plus_enc_batch_last_kernel_ms",
+    "lc3plus_enc_batch_set_bandwidth", "lc3plus_enc_batch_encode", "lc3plus_enc_batch_last_kernel_ms", "lc3plus_enc_batch_last_status",
     "lc3plus_enc_init", "lc3plus_enc_set_frame_ms", "lc3plus_enc_set_hrmode", "lc3plus_enc_set_bitrate",
     "lc3plus_enc16", "lc3plus_enc_get_size",
     "lc3_dec_get_size", "lc3_dec_init", "lc3_dec_set_frame_ms", "lc3_dec_set_hrmode", "lc3_dec_get_output_samples",
@@ -57,6 +57,7 @@ def load_library():
         L.lc3plus_enc_batch_encode_traced.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
         L.lc3plus_enc_batch_last_kernel_ms.restype = C.c_float
         L.lc3plus_enc_batch_last_kernel_ms.argtypes = [C.c_void_p]
+        L.lc3plus_enc_batch_last_status.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         for f in ("lc3plus_enc_batch_destroy", "lc3plus_enc_batch_input_samples", "lc3plus_enc_batch_stride"):
             getattr(L, f).argtypes = [C.c_void_p]
         L.lc3plus_enc_batch_num_bytes.argtypes = [C.c_void_p, C.c_int]
@@ -121,6 +122,24 @@ class Batch:
         if rc:
             raise LC3Error(rc, "lc3plus_enc_batch_encode")
         return out
+
+    def encode_host(self, pcm, out, bitdepth=16):
+        """Host buffers supplied by the caller (numpy views of pinned or pageable memory): pcm [n_streams, T, channels, N] ->
+        out uint8 [n_streams, T, >= stride] in place; the library overlaps the copies with the kernels."""
+        assert pcm.flags.c_contiguous and out.flags.c_contiguous and out.dtype == np.uint8
+        T = pcm.shape[1]
+        rc = self.lib.lc3plus_enc_batch_encode(self.h, pcm.ctypes.data, 0, bitdepth, T, out.ctypes.data, out.shape[2], 0, None, 1)
+        if rc:
+            raise LC3Error(rc, "lc3plus_enc_batch_encode(host)")
+        return out
+
+    def last_status(self, T):
+        """uint8 [n_streams * channels, T]: LC3D_ENC_ST_* bits of the last call (0 = nothing the reference would assert on)."""
+        st = np.zeros((self.n_streams * self.channels, T), dtype=np.uint8)
+        n = self.lib.lc3plus_enc_batch_last_status(self.h, st.ctypes.data, st.size)
+        if n < 0:
+            raise LC3Error(1, "lc3plus_enc_batch_last_status")
+        return st
 
     def encode_traced(self, pcm, bitdepth=16):
         pcm = np.ascontiguousarray(pcm)

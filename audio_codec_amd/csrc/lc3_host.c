@@ -8,6 +8,7 @@
  * call fails with LC3_ERROR.
  */
 #include <math.h>
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -398,13 +399,28 @@ LC3_Error lc3plus_enc_batch_encode_traced(lc3plus_batch* b, const void* pcm, int
 int lc3plus_trace_sizeof(void) { return (int)sizeof(lc3d_trace); }
 
 float lc3plus_enc_batch_last_kernel_ms(lc3plus_batch* b) { return b ? lc3hip_last_ms(b->dev) : 0.0f; }
+int lc3plus_enc_batch_last_status(lc3plus_batch* b, uint8_t* status, int max_entries)
+{
+    if (!b || !status || max_entries < 0) return -1;
+    return lc3hip_last_status(b->dev, status, max_entries);
+}
 
 /* ------------------------------------------------------------------------------------------------ */
 /* single-stream drop-in API (R/lc3.h:163-295)                                                       */
 /* ------------------------------------------------------------------------------------------------ */
 struct LC3_Enc {
-    /* R/codec_exe.c:298-320 reads these three fields of the reference struct directly; keep the names */
-    int bitrate, epmode, bandwidth;
+    /* R/codec_exe.c is not a pure client of the opaque API: compiled against the reference's own headers it reads encoder->bitrate
+     * (:298-299), ->epmode (:310-312) and ->bandwidth (:320) directly, i.e. the words at byte offsets 48, 64 and 144 of the
+     * reference's struct (R/setup_enc_lc3.h:65-104 on LP64: five pointers, then ints).  The three fields sit at those offsets here
+     * so that the unmodified CLI relinks against this library (`make relink`); the words between them are unused. */
+    void* ref_ptr[5];               /*   0 ..  39 */
+    int ref_w40[2];                 /*  40 ..  47 */
+    int bitrate;                    /*  48 */
+    int ref_w52[3];                 /*  52 ..  63 */
+    int epmode;                     /*  64 */
+    int ref_w68[19];                /*  68 .. 143 */
+    int bandwidth;                  /* 144 */
+    int ref_w148[7];                /* 148 .. 175: the rest of the reference struct's 176 bytes */
     int lc3_br_set, channels, samplerate, hrmode; float frame_ms;
     geom_t g;
     lc3d_chan ch[MAX_CH];
@@ -412,6 +428,8 @@ struct LC3_Enc {
     int16_t* stage16; int32_t* stage32; uint8_t* stage_out;
     unsigned magic;
 };
+_Static_assert(offsetof(struct LC3_Enc, bitrate) == 48 && offsetof(struct LC3_Enc, epmode) == 64 && offsetof(struct LC3_Enc, bandwidth) == 144,
+               "fields R/codec_exe.c reads must sit at the reference's offsets");
 #define ENC_MAGIC 0x4C433350u
 
 int lc3_version(void) { return LC3_VERSION; }
@@ -524,7 +542,7 @@ LC3_Error lc3_enc_fl(LC3_Enc* e, void** input_samples, int bitdepth, void* outpu
         e->stage16 = (int16_t*)malloc(sizeof(int16_t) * C * LC3D_MAX_N);
         e->stage32 = (int32_t*)malloc(sizeof(int32_t) * C * LC3D_MAX_N);
         e->stage_out = (uint8_t*)malloc(LC3_MAX_BYTES);
-        if (!e->stage16 || !e->stage32 || !e->stage_out) return LC3_ERROR;
+        if (!e->stage16 || !e->stage32 || !e->stage_out) { enc_drop_device(e); return LC3_ERROR; }
     }
     const void* pcm;
     if (bitdepth == 16) { for (int c = 0; c < C; c++) memcpy(e->stage16 + c * N, input_samples[c], sizeof(int16_t) * N); pcm = e->stage16; }
@@ -789,7 +807,7 @@ LC3_Error lc3_dec_fl(LC3_Dec* d, void* input_bytes, int num_bytes, void** output
         if (err) return err;
         d->stage_in = (uint8_t*)malloc(LC3_MAX_BYTES);
         d->stage_pcm = malloc(sizeof(int32_t) * C * LC3D_MAX_N);
-        if (!d->stage_in || !d->stage_pcm) return LC3_ERROR;
+        if (!d->stage_in || !d->stage_pcm) { dec_drop_device(d); return LC3_ERROR; }
     }
     int bfi = bfi_ext;
     if (bfi == 0) bfi = !num_bytes;                                        /* R/dec_lc3_fl.c:140-143 */

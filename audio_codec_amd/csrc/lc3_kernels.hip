@@ -2443,7 +2443,8 @@ extern "C" __global__ void __launch_bounds__(WAVE) __attribute__((amdgpu_waves_p
 KERNEL_NAME(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans, float* __restrict__ state,
                   const void* __restrict__ pcm, int bitdepth, int T, uint8_t* __restrict__ out, int out_stride, int ncs,
                   lc3d_trace* __restrict__ trace, int* __restrict__ dump /* [cs][T][dstride] hand-over to lc3_enc_pack_kernel, or null: write the bytes here */, int dstride,
-                  const float* __restrict__ y12 /* [cs][T][128] HP-filtered 12.8 kHz signal from the pre-kernels, or null: resample here */)
+                  const float* __restrict__ y12 /* [cs][T][128] HP-filtered 12.8 kHz signal from the pre-kernels, or null: resample here */,
+                  uint8_t* __restrict__ status /* [cs][T] LC3D_ENC_ST_* bits (zeroed by the host), or null */)
 {
     __shared__ WaveLds L;
     const int lane = threadIdx.x;
@@ -2588,7 +2589,17 @@ KERNEL_NAME(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans
             for (int i = lane; i < nresw; i += WAVE) r[PK_RES + i] = (int)((const uint32_t*)RESB(L))[i];
             const int* xq = XQ(L);
             if (PI(hrmode)) { for (int i = lane; i < ((lastnz + 1) & ~1); i += WAVE) r[PK_XQ + i] = xq[i]; }
-            else for (int p = lane; p < ((lastnz + 1) >> 1); p += WAVE) r[PK_XQ + p] = (xq[2 * p] & 0xFFFF) | (xq[2 * p + 1] << 16);
+            else {
+                /* R/quantize_spec.c:50 asserts that a quantised line fits 16 bits outside the high-resolution mode; here the frame is
+                 * flagged instead (the hand-over keeps the low 16 bits) */
+                bool ovf = false;
+                for (int p = lane; p < ((lastnz + 1) >> 1); p += WAVE) {
+                    const int q0 = xq[2 * p], q1 = xq[2 * p + 1];
+                    ovf |= q0 != (int)(int16_t)q0 || q1 != (int)(int16_t)q1;
+                    r[PK_XQ + p] = (q0 & 0xFFFF) | (q1 << 16);
+                }
+                if (status && __ballot(ovf) && lane == 0) status[(size_t)cs * T + t] |= LC3D_ENC_ST_QUANT_RANGE;
+            }
             LSYNC();
             TICK(16);
             TICK(17);
@@ -2626,7 +2637,8 @@ KERNEL_NAME(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans
 #include "lc3_dec_parse.inc"
 extern "C" __global__ void lc3_encode_kernel_big(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans, float* __restrict__ state,
                                                  const void* __restrict__ pcm, int bitdepth, int T, uint8_t* __restrict__ out, int out_stride, int ncs,
-                                                 lc3d_trace* __restrict__ trace, int* __restrict__ dump, int dstride, const float* __restrict__ y12);
+                                                 lc3d_trace* __restrict__ trace, int* __restrict__ dump, int dstride, const float* __restrict__ y12,
+                                                 uint8_t* __restrict__ status);
 #include "lc3_enc_pack.inc"
 #include "lc3_enc_pre.inc"
 struct lc3hip_ctx {
@@ -2634,32 +2646,40 @@ struct lc3hip_ctx {
     lc3d_plan* d_plan; lc3d_chan* d_chans; float* d_state;
     void* d_pcm; size_t pcm_cap; uint8_t* d_out; size_t out_cap;
     lc3d_trace* d_trace; size_t trace_cap;
-    int* d_dump; size_t dump_cap; int hr, max_nbytes, fused; float* d_y12; size_t y12_cap;
-    hipStream_t stream; hipEvent_t ev0, ev1; float last_ms;
+    int* d_dump; size_t dump_cap; int hr, fused; float* d_y12; size_t y12_cap;
+    uint8_t* d_status; size_t status_cap; int status_frames;      /* per channel-frame status bits of the last call (LC3D_ENC_ST_*) */
+    /* host-pointer pipeline (lc3hip_encode_host): two chunk slots, each with device staging and (for pageable callers) pinned staging */
+    void* hp_dpcm[2]; uint8_t* hp_dout[2]; void* hp_pin_in[2]; uint8_t* hp_pin_out[2]; size_t hp_pcm_cap, hp_out_cap, hp_pin_in_cap, hp_pin_out_cap;
+    hipStream_t s_h2d, s_d2h; hipEvent_t ev_h2d[2], ev_k[2], ev_d2h[2];
+    hipStream_t stream, last_stream; hipEvent_t ev0, ev1; float last_ms;
 };
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "lc3plus_hip: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); return 1; } } while (0)
+/* inside the create functions: release what has been allocated so far (the caller only sees ctx == NULL) */
+#define HIPCHK_OR(x, cleanup) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "lc3plus_hip: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); cleanup; return 1; } } while (0)
 
+extern "C" int lc3hip_destroy(void* ctx);
 extern "C" int lc3hip_create(void** out_ctx, const lc3d_plan* plan, int n_streams, int device)
 {
     int ndev = 0;
+    *out_ctx = nullptr;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { fprintf(stderr, "lc3plus_hip: no HIP device available (this engine has no CPU fallback)\n"); return 1; }
     lc3hip_ctx* c = (lc3hip_ctx*)calloc(1, sizeof *c);
     if (!c) return 1;
     if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
     c->device = device;
-    HIPCHK(hipSetDevice(device));
+    HIPCHK_OR(hipSetDevice(device), free(c));
     c->n_streams = n_streams; c->channels = plan->channels; c->ncs = n_streams * plan->channels; c->N = plan->N;
     c->big = LC3D_LAYOUT_BIG(plan->N, plan->la);
     c->hr = plan->hrmode;
     { const char* e = getenv("LC3PLUS_ENC_FUSED"); c->fused = e && e[0] == '1'; }     /* diagnostic: the bitstream writer inside lc3_encode_kernel */
     c->state_words = LC3D_STATE_WORDS(c->big ? LC3D_MEMCAP_BIG : LC3D_MEMCAP_STD);
-    HIPCHK(hipMalloc((void**)&c->d_plan, sizeof(lc3d_plan)));
-    HIPCHK(hipMemcpy(c->d_plan, plan, sizeof(lc3d_plan), hipMemcpyHostToDevice));
-    HIPCHK(hipMalloc((void**)&c->d_chans, sizeof(lc3d_chan) * c->ncs));
-    HIPCHK(hipMalloc((void**)&c->d_state, sizeof(float) * c->state_words * (size_t)c->ncs));
-    HIPCHK(hipStreamCreate(&c->stream));
-    HIPCHK(hipEventCreate(&c->ev0)); HIPCHK(hipEventCreate(&c->ev1));
+    HIPCHK_OR(hipMalloc((void**)&c->d_plan, sizeof(lc3d_plan)), lc3hip_destroy(c));
+    HIPCHK_OR(hipMemcpy(c->d_plan, plan, sizeof(lc3d_plan), hipMemcpyHostToDevice), lc3hip_destroy(c));
+    HIPCHK_OR(hipMalloc((void**)&c->d_chans, sizeof(lc3d_chan) * c->ncs), lc3hip_destroy(c));
+    HIPCHK_OR(hipMalloc((void**)&c->d_state, sizeof(float) * c->state_words * (size_t)c->ncs), lc3hip_destroy(c));
+    HIPCHK_OR(hipStreamCreate(&c->stream), lc3hip_destroy(c));
+    HIPCHK_OR(hipEventCreate(&c->ev0), lc3hip_destroy(c)); HIPCHK_OR(hipEventCreate(&c->ev1), lc3hip_destroy(c));
     *out_ctx = c;
     return 0;
 }
@@ -2682,8 +2702,138 @@ extern "C" int lc3hip_upload_chans(void* ctx, const lc3d_chan* chans, int first,
 {
     lc3hip_ctx* c = (lc3hip_ctx*)ctx;
     HIPCHK(hipSetDevice(c->device));
+    /* a launch with sync = 0 may still be reading d_chans, possibly on a caller's non-blocking stream that a plain hipMemcpy does not
+     * wait for: drain the stream the last launch went to first */
+    if (c->last_stream) { HIPCHK(hipStreamSynchronize(c->last_stream)); c->last_stream = nullptr; }
     HIPCHK(hipMemcpy(c->d_chans + first, chans, sizeof(lc3d_chan) * count, hipMemcpyHostToDevice));
-    for (int i = 0; i < count; i++) if (chans[i].nbytes > c->max_nbytes) c->max_nbytes = chans[i].nbytes;
+    return 0;
+}
+
+/* the kernels of one call on stream s: PCM and output both in device memory */
+static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frames, uint8_t* dout, int out_stride, hipStream_t s, lc3d_trace* dtr)
+{
+    /* two kernels: lc3_encode_kernel (one wave per channel-stream, frames in order) leaves each frame's parameters and quantised
+     * spectrum in a record; lc3_enc_pack_kernel (one channel-frame per lane, any frame size) writes the bytes.  With stage traces,
+     * or with LC3PLUS_ENC_FUSED=1 (diagnostic), the first kernel writes the bytes itself. */
+    int* ddump = nullptr; int dstride = 0;
+    if (!dtr && !c->fused) {
+        dstride = PK_STRIDE(c->N, c->hr);
+        const size_t need = (size_t)c->ncs * n_frames * dstride;
+        if (c->dump_cap < need) { if (c->d_dump) HIPCHK(hipFree(c->d_dump)); c->d_dump = nullptr; c->dump_cap = 0; HIPCHK(hipMalloc((void**)&c->d_dump, need * sizeof(int))); c->dump_cap = need; }
+        ddump = c->d_dump;
+    }
+    /* ahead of it: the 12.8 kHz resampler of all frames at once and its HP50 recurrence one stream per lane (lc3_enc_pre.inc) */
+    float* dy12 = nullptr;
+    if (!dtr && !c->fused) {
+        const size_t need = (size_t)c->ncs * n_frames * 128;
+        if (c->y12_cap < need) { if (c->d_y12) HIPCHK(hipFree(c->d_y12)); c->d_y12 = nullptr; c->y12_cap = 0; HIPCHK(hipMalloc((void**)&c->d_y12, need * sizeof(float))); c->y12_cap = need; }
+        dy12 = c->d_y12;
+    }
+    {   /* per channel-frame status bits (LC3D_ENC_ST_*), cleared per call */
+        const size_t need = (size_t)c->ncs * n_frames;
+        if (c->status_cap < need) { if (c->d_status) HIPCHK(hipFree(c->d_status)); c->d_status = nullptr; c->status_cap = 0; HIPCHK(hipMalloc((void**)&c->d_status, need)); c->status_cap = need; }
+        HIPCHK(hipMemsetAsync(c->d_status, 0, need, s));
+        c->status_frames = n_frames;
+    }
+    if (dy12) {
+        const int mc = c->big ? LC3D_MEMCAP_BIG : LC3D_MEMCAP_STD;
+        const unsigned runs = (unsigned)((n_frames + PRE_FPW - 1) / PRE_FPW);
+        hipLaunchKernelGGL(lc3_enc_resample_kernel, dim3((unsigned)c->ncs * runs), dim3(WAVE), 0, s, c->d_plan, c->d_state, c->state_words, mc, dpcm, bitdepth, n_frames, c->ncs, dy12);
+        hipLaunchKernelGGL(lc3_enc_hp50_kernel, dim3((unsigned)((c->ncs + WAVE - 1) / WAVE)), dim3(WAVE), 0, s, c->d_plan, c->d_state, c->state_words, LC3D_ST_SCAL(mc), n_frames, c->ncs, dy12);
+        HIPCHK(hipGetLastError());
+    }
+    if (c->big) hipLaunchKernelGGL(lc3_encode_kernel_big, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames,
+                                   dout, out_stride, c->ncs, dtr, ddump, dstride, dy12, c->d_status);
+    else hipLaunchKernelGGL(lc3_encode_kernel, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames,
+                            dout, out_stride, c->ncs, dtr, ddump, dstride, dy12, c->d_status);
+    if (ddump) {
+        HIPCHK(hipGetLastError());
+        const int wpg = 4;
+        const size_t per_wave = (size_t)PK_XBUF * WAVE * sizeof(unsigned);
+        const long long tasks = (long long)c->ncs * n_frames, per_wg = (long long)wpg * WAVE;
+        hipLaunchKernelGGL(lc3_enc_pack_kernel, dim3((unsigned)((tasks + per_wg - 1) / per_wg)), dim3(wpg * WAVE), per_wave * wpg, s, c->d_plan, c->d_chans, ddump, dstride,
+                           n_frames, c->ncs, dout, out_stride, c->d_status);
+    }
+    HIPCHK(hipGetLastError());
+    c->last_stream = s;
+    return 0;
+}
+
+static bool host_ptr_is_pinned(const void* p)
+{
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+
+/* Host pointers on both sides (SURVEY 8d "wall-clock over the encode() call including H2D of PCM and D2H of bitstreams"): the call is
+ * cut into runs of frames (all streams advance together, so every run fills the GPU like the whole call would; cutting by streams
+ * would not); run k's PCM goes up on one stream while run k-1 is encoded on the launch stream and run k-2's frames come down on a
+ * third.  PCM of a run is a strided block of the caller's [stream][frame][channel][N] array: a 2-D copy straight from / to the
+ * caller's memory when that is pinned (hipHostMalloc / hipHostRegister), otherwise rows are staged through the library's own pinned
+ * slots by the calling thread, which overlaps with the GPU work of the previous run.  State stays on the device between runs. */
+static int encode_host(lc3hip_ctx* c, const void* pcm, int bitdepth, int n_frames, void* out, int out_stride, hipStream_t s)
+{
+    const size_t bps = bitdepth == 16 ? 2 : 4;
+    const size_t fr_in = (size_t)c->channels * c->N * bps;                    /* bytes of one stream-frame of PCM */
+    const size_t pcm_bytes = (size_t)c->n_streams * n_frames * fr_in;
+    int K = (int)(pcm_bytes >> 25);                                           /* ~32 MB of PCM per run */
+    if (K < 1) K = 1; if (K > 8) K = 8; if (K > n_frames) K = n_frames;
+    const int Tc = (n_frames + K - 1) / K;
+    const bool pin_in = host_ptr_is_pinned(pcm), pin_out = host_ptr_is_pinned(out);
+    const size_t cin = (size_t)c->n_streams * Tc * fr_in, cout = (size_t)c->n_streams * Tc * out_stride;
+    if (!c->s_h2d) {
+        HIPCHK(hipStreamCreateWithFlags(&c->s_h2d, hipStreamNonBlocking)); HIPCHK(hipStreamCreateWithFlags(&c->s_d2h, hipStreamNonBlocking));
+        for (int i = 0; i < 2; i++) { HIPCHK(hipEventCreateWithFlags(&c->ev_h2d[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_k[i], hipEventDisableTiming));
+                                      HIPCHK(hipEventCreateWithFlags(&c->ev_d2h[i], hipEventDisableTiming)); }
+    }
+    if (c->hp_pcm_cap < cin) { for (int i = 0; i < 2; i++) { if (c->hp_dpcm[i]) HIPCHK(hipFree(c->hp_dpcm[i])); c->hp_dpcm[i] = nullptr; } c->hp_pcm_cap = 0;
+                               for (int i = 0; i < 2; i++) HIPCHK(hipMalloc(&c->hp_dpcm[i], cin)); c->hp_pcm_cap = cin; }
+    if (c->hp_out_cap < cout) { for (int i = 0; i < 2; i++) { if (c->hp_dout[i]) HIPCHK(hipFree(c->hp_dout[i])); c->hp_dout[i] = nullptr; } c->hp_out_cap = 0;
+                                for (int i = 0; i < 2; i++) HIPCHK(hipMalloc((void**)&c->hp_dout[i], cout)); c->hp_out_cap = cout; }
+    if (!pin_in && c->hp_pin_in_cap < cin) { for (int i = 0; i < 2; i++) { if (c->hp_pin_in[i]) HIPCHK(hipHostFree(c->hp_pin_in[i])); c->hp_pin_in[i] = nullptr; } c->hp_pin_in_cap = 0;
+                                             for (int i = 0; i < 2; i++) HIPCHK(hipHostMalloc(&c->hp_pin_in[i], cin, hipHostMallocDefault)); c->hp_pin_in_cap = cin; }
+    if (!pin_out && c->hp_pin_out_cap < cout) { for (int i = 0; i < 2; i++) { if (c->hp_pin_out[i]) HIPCHK(hipHostFree(c->hp_pin_out[i])); c->hp_pin_out[i] = nullptr; } c->hp_pin_out_cap = 0;
+                                                for (int i = 0; i < 2; i++) HIPCHK(hipHostMalloc((void**)&c->hp_pin_out[i], cout, hipHostMallocDefault)); c->hp_pin_out_cap = cout; }
+    const size_t in_pitch = (size_t)n_frames * fr_in, out_pitch = (size_t)n_frames * out_stride;
+    HIPCHK(hipEventRecord(c->ev0, s));
+    int pend_t0[2] = {0, 0}, pend_tc[2] = {0, 0};                             /* runs whose frames still sit in a pinned output slot */
+    for (int k = 0, t0 = 0; t0 < n_frames; k++, t0 += Tc) {
+        const int i = k & 1, tc = n_frames - t0 < Tc ? n_frames - t0 : Tc;
+        const size_t w_in = (size_t)tc * fr_in, w_out = (size_t)tc * out_stride;
+        if (k >= 2) {                                                          /* slot i was used by run k - 2 */
+            HIPCHK(hipEventSynchronize(c->ev_d2h[i]));                         /* its kernels and copies are done: both staging slots are free */
+            if (!pin_out) for (int st = 0; st < c->n_streams; st++)
+                memcpy((uint8_t*)out + st * out_pitch + (size_t)pend_t0[i] * out_stride, c->hp_pin_out[i] + (size_t)st * pend_tc[i] * out_stride, (size_t)pend_tc[i] * out_stride);
+        }
+        const uint8_t* src = (const uint8_t*)pcm + (size_t)t0 * fr_in;
+        if (pin_in) HIPCHK(hipMemcpy2DAsync(c->hp_dpcm[i], w_in, src, in_pitch, w_in, (size_t)c->n_streams, hipMemcpyHostToDevice, c->s_h2d));
+        else {
+            for (int st = 0; st < c->n_streams; st++) memcpy((uint8_t*)c->hp_pin_in[i] + st * w_in, src + st * in_pitch, w_in);
+            HIPCHK(hipMemcpyAsync(c->hp_dpcm[i], c->hp_pin_in[i], w_in * c->n_streams, hipMemcpyHostToDevice, c->s_h2d));
+        }
+        HIPCHK(hipEventRecord(c->ev_h2d[i], c->s_h2d));
+        HIPCHK(hipStreamWaitEvent(s, c->ev_h2d[i], 0));
+        HIPCHK(hipMemsetAsync(c->hp_dout[i], 0, w_out * c->n_streams, s));
+        if (enc_launch(c, c->hp_dpcm[i], bitdepth, tc, c->hp_dout[i], out_stride, s, nullptr)) return 1;
+        HIPCHK(hipEventRecord(c->ev_k[i], s));
+        HIPCHK(hipStreamWaitEvent(c->s_d2h, c->ev_k[i], 0));
+        if (pin_out) HIPCHK(hipMemcpy2DAsync((uint8_t*)out + (size_t)t0 * out_stride, out_pitch, c->hp_dout[i], w_out, w_out, (size_t)c->n_streams, hipMemcpyDeviceToHost, c->s_d2h));
+        else HIPCHK(hipMemcpyAsync(c->hp_pin_out[i], c->hp_dout[i], w_out * c->n_streams, hipMemcpyDeviceToHost, c->s_d2h));
+        HIPCHK(hipEventRecord(c->ev_d2h[i], c->s_d2h));
+        pend_t0[i] = t0; pend_tc[i] = tc;
+    }
+    HIPCHK(hipEventRecord(c->ev1, s));
+    const int runs = (n_frames + Tc - 1) / Tc;
+    for (int k = runs > 2 ? runs - 2 : 0; k < runs; k++) {
+        const int i = k & 1;
+        HIPCHK(hipEventSynchronize(c->ev_d2h[i]));
+        if (!pin_out) for (int st = 0; st < c->n_streams; st++)
+            memcpy((uint8_t*)out + st * out_pitch + (size_t)pend_t0[i] * out_stride, c->hp_pin_out[i] + (size_t)st * pend_tc[i] * out_stride, (size_t)pend_tc[i] * out_stride);
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    /* the status bytes of a host call are those of its last run only when it was cut; callers that want them use one run (n_frames <= 8 or device pointers) */
+    float ms = 0; if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->last_ms = ms;
     return 0;
 }
 
@@ -2693,70 +2843,30 @@ extern "C" int lc3hip_encode(void* ctx, const void* pcm, int pcm_on_device, int 
     lc3hip_ctx* c = (lc3hip_ctx*)ctx;
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    if (!pcm_on_device && !out_on_device && !trace_host) return encode_host(c, pcm, bitdepth, n_frames, out, out_stride, s);
     const size_t bps = bitdepth == 16 ? 2 : 4;
     const size_t pcm_bytes = (size_t)c->n_streams * n_frames * c->channels * c->N * bps;
     const size_t out_bytes = (size_t)c->n_streams * n_frames * out_stride;
     const void* dpcm = pcm; uint8_t* dout = (uint8_t*)out;
     if (!pcm_on_device) {
-        if (c->pcm_cap < pcm_bytes) { if (c->d_pcm) HIPCHK(hipFree(c->d_pcm)); HIPCHK(hipMalloc(&c->d_pcm, pcm_bytes)); c->pcm_cap = pcm_bytes; }
+        if (c->pcm_cap < pcm_bytes) { if (c->d_pcm) HIPCHK(hipFree(c->d_pcm)); c->d_pcm = nullptr; c->pcm_cap = 0; HIPCHK(hipMalloc(&c->d_pcm, pcm_bytes)); c->pcm_cap = pcm_bytes; }
         HIPCHK(hipMemcpyAsync(c->d_pcm, pcm, pcm_bytes, hipMemcpyHostToDevice, s));
         dpcm = c->d_pcm;
     }
     if (!out_on_device) {
-        if (c->out_cap < out_bytes) { if (c->d_out) HIPCHK(hipFree(c->d_out)); HIPCHK(hipMalloc((void**)&c->d_out, out_bytes)); c->out_cap = out_bytes; }
+        if (c->out_cap < out_bytes) { if (c->d_out) HIPCHK(hipFree(c->d_out)); c->d_out = nullptr; c->out_cap = 0; HIPCHK(hipMalloc((void**)&c->d_out, out_bytes)); c->out_cap = out_bytes; }
         dout = c->d_out;
         HIPCHK(hipMemsetAsync(dout, 0, out_bytes, s));
     }
     lc3d_trace* dtr = nullptr;
     if (trace_host) {
         const size_t tb = sizeof(lc3d_trace) * (size_t)c->ncs * n_frames;
-        if (c->trace_cap < tb) { if (c->d_trace) HIPCHK(hipFree(c->d_trace)); HIPCHK(hipMalloc((void**)&c->d_trace, tb)); c->trace_cap = tb; }
+        if (c->trace_cap < tb) { if (c->d_trace) HIPCHK(hipFree(c->d_trace)); c->d_trace = nullptr; c->trace_cap = 0; HIPCHK(hipMalloc((void**)&c->d_trace, tb)); c->trace_cap = tb; }
         HIPCHK(hipMemsetAsync(c->d_trace, 0, tb, s));
         dtr = c->d_trace;
     }
-    /* two kernels: lc3_encode_kernel (one wave per channel-stream, frames in order) leaves each frame's parameters and quantised
-     * spectrum in a record; lc3_enc_pack_kernel (one channel-frame per lane) writes the bytes.  With stage traces, or with
-     * LC3PLUS_ENC_FUSED=1, the first kernel writes the bytes itself. */
-    int* ddump = nullptr; int dstride = 0;
-    /* frames above 128 bytes would leave the pack kernel one wave per SIMD (its LDS staging is sized by the largest frame of the
-     * batch): such batches keep the single-kernel path */
-    if (!trace_host && !c->fused && c->max_nbytes <= 128) {
-        dstride = PK_STRIDE(c->N, c->hr);
-        const size_t need = (size_t)c->ncs * n_frames * dstride;
-        if (c->dump_cap < need) { if (c->d_dump) HIPCHK(hipFree(c->d_dump)); c->d_dump = nullptr; c->dump_cap = 0; HIPCHK(hipMalloc((void**)&c->d_dump, need * sizeof(int))); c->dump_cap = need; }
-        ddump = c->d_dump;
-    }
-    /* ahead of it: the 12.8 kHz resampler of all frames at once and its HP50 recurrence one stream per lane (lc3_enc_pre.inc) */
-    float* dy12 = nullptr;
-    if (!trace_host && !c->fused) {
-        const size_t need = (size_t)c->ncs * n_frames * 128;
-        if (c->y12_cap < need) { if (c->d_y12) HIPCHK(hipFree(c->d_y12)); c->d_y12 = nullptr; c->y12_cap = 0; HIPCHK(hipMalloc((void**)&c->d_y12, need * sizeof(float))); c->y12_cap = need; }
-        dy12 = c->d_y12;
-    }
     HIPCHK(hipEventRecord(c->ev0, s));
-    if (dy12) {
-        const int mc = c->big ? LC3D_MEMCAP_BIG : LC3D_MEMCAP_STD;
-        const unsigned runs = (unsigned)((n_frames + PRE_FPW - 1) / PRE_FPW);
-        hipLaunchKernelGGL(lc3_enc_resample_kernel, dim3((unsigned)c->ncs * runs), dim3(WAVE), 0, s, c->d_plan, c->d_state, c->state_words, mc, dpcm, bitdepth, n_frames, c->ncs, dy12);
-        hipLaunchKernelGGL(lc3_enc_hp50_kernel, dim3((unsigned)((c->ncs + WAVE - 1) / WAVE)), dim3(WAVE), 0, s, c->d_plan, c->d_state, c->state_words, LC3D_ST_SCAL(mc), n_frames, c->ncs, dy12);
-        HIPCHK(hipGetLastError());
-    }
-    if (c->big) hipLaunchKernelGGL(lc3_encode_kernel_big, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames,
-                                   dout, out_stride, c->ncs, dtr, ddump, dstride, dy12);
-    else hipLaunchKernelGGL(lc3_encode_kernel, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames,
-                            dout, out_stride, c->ncs, dtr, ddump, dstride, dy12);
-    if (ddump) {
-        HIPCHK(hipGetLastError());
-        const int nw_max = c->max_nbytes > 0 ? (c->max_nbytes + 3) / 4 : 1;
-        const size_t per_wave = (size_t)(nw_max + PK_XBUF) * WAVE * sizeof(unsigned);
-        int wpg = (int)((64 * 1024 - sizeof(PackLds)) / per_wave);
-        if (wpg > 4) wpg = 4;
-        if (wpg < 1) { fprintf(stderr, "lc3plus_hip: frame of %d bytes exceeds the pack kernel's LDS staging\n", c->max_nbytes); return 1; }
-        const long long tasks = (long long)c->ncs * n_frames, per_wg = (long long)wpg * WAVE;
-        hipLaunchKernelGGL(lc3_enc_pack_kernel, dim3((unsigned)((tasks + per_wg - 1) / per_wg)), dim3(wpg * WAVE), per_wave * wpg, s, c->d_plan, c->d_chans, ddump, dstride,
-                           n_frames, c->ncs, nw_max, dout, out_stride);
-    }
-    HIPCHK(hipGetLastError());
+    if (enc_launch(c, dpcm, bitdepth, n_frames, dout, out_stride, s, dtr)) return 1;
     HIPCHK(hipEventRecord(c->ev1, s));
     if (!out_on_device) HIPCHK(hipMemcpyAsync(out, dout, out_bytes, hipMemcpyDeviceToHost, s));
     if (trace_host) HIPCHK(hipMemcpyAsync(trace_host, dtr, sizeof(lc3d_trace) * (size_t)c->ncs * n_frames, hipMemcpyDeviceToHost, s));
@@ -2765,6 +2875,17 @@ extern "C" int lc3hip_encode(void* ctx, const void* pcm, int pcm_on_device, int 
         float ms = 0; if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->last_ms = ms;
     }
     return 0;
+}
+
+/* status bits of the last call, [channel-stream][frame] (n = ncs * frames of that call), to host memory */
+extern "C" int lc3hip_last_status(void* ctx, uint8_t* status_host, int n)
+{
+    lc3hip_ctx* c = (lc3hip_ctx*)ctx;
+    HIPCHK(hipSetDevice(c->device));
+    if (n > c->ncs * c->status_frames) n = c->ncs * c->status_frames;
+    if (c->last_stream) HIPCHK(hipStreamSynchronize(c->last_stream));
+    if (n > 0) HIPCHK(hipMemcpy(status_host, c->d_status, (size_t)n, hipMemcpyDeviceToHost));
+    return n;
 }
 
 extern "C" float lc3hip_last_ms(void* ctx)
@@ -2780,7 +2901,7 @@ extern "C" int lc3hip_destroy(void* ctx)
     lc3hip_ctx* c = (lc3hip_ctx*)ctx;
     if (!c) return 0;
     hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
+    hipDeviceSynchronize();
     if (c->d_plan) hipFree(c->d_plan);
     if (c->d_chans) hipFree(c->d_chans);
     if (c->d_state) hipFree(c->d_state);
@@ -2789,8 +2910,21 @@ extern "C" int lc3hip_destroy(void* ctx)
     if (c->d_dump) hipFree(c->d_dump);
     if (c->d_y12) hipFree(c->d_y12);
     if (c->d_trace) hipFree(c->d_trace);
-    hipEventDestroy(c->ev0); hipEventDestroy(c->ev1);
-    hipStreamDestroy(c->stream);
+    if (c->d_status) hipFree(c->d_status);
+    for (int i = 0; i < 2; i++) {
+        if (c->hp_dpcm[i]) hipFree(c->hp_dpcm[i]);
+        if (c->hp_dout[i]) hipFree(c->hp_dout[i]);
+        if (c->hp_pin_in[i]) hipHostFree(c->hp_pin_in[i]);
+        if (c->hp_pin_out[i]) hipHostFree(c->hp_pin_out[i]);
+        if (c->ev_h2d[i]) hipEventDestroy(c->ev_h2d[i]);
+        if (c->ev_k[i]) hipEventDestroy(c->ev_k[i]);
+        if (c->ev_d2h[i]) hipEventDestroy(c->ev_d2h[i]);
+    }
+    if (c->s_h2d) hipStreamDestroy(c->s_h2d);
+    if (c->s_d2h) hipStreamDestroy(c->s_d2h);
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); }
     free(c);
     return 0;
 }
@@ -2805,37 +2939,39 @@ struct lc3hip_dctx {
     lc3d_plan* d_plan; lc3d_dchan* d_chans; float* d_state;
     uint8_t* d_in; size_t in_cap; void* d_pcm; size_t pcm_cap; uint8_t* d_bfi; size_t bfi_cap;
     lc3d_dec_trace* d_trace; size_t trace_cap; uint8_t* d_status; size_t status_cap;
-    int* d_rec; float* d_ws; float* d_ov; size_t hand_cap; int max_nbytes;
-    hipStream_t stream; hipEvent_t ev0, ev1; float last_ms;
+    int* d_rec; float* d_ws; float* d_ov; size_t hand_cap; int max_nbytes; int* h_nbytes;
+    hipStream_t stream, last_stream; hipEvent_t ev0, ev1; float last_ms;
 };
+extern "C" int lc3hip_dec_destroy(void* ctx);
 extern "C" int lc3hip_dec_create(void** out_ctx, const lc3d_plan* plan, int n_streams, int device)
 {
     int ndev = 0;
+    *out_ctx = nullptr;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { fprintf(stderr, "lc3plus_hip: no HIP device available (this engine has no CPU fallback)\n"); return 1; }
     lc3hip_dctx* c = (lc3hip_dctx*)calloc(1, sizeof *c);
     if (!c) return 1;
     if (device < 0) { if (hipGetDevice(&device) != hipSuccess) device = 0; }
     c->device = device;
-    HIPCHK(hipSetDevice(device));
+    HIPCHK_OR(hipSetDevice(device), free(c));
     c->n_streams = n_streams; c->channels = plan->channels; c->ncs = n_streams * plan->channels; c->N = plan->N;
     c->big = LC3D_LAYOUT_BIG(plan->N, plan->la);
-    HIPCHK(hipMalloc((void**)&c->d_plan, sizeof(lc3d_plan)));
-    HIPCHK(hipMemcpy(c->d_plan, plan, sizeof(lc3d_plan), hipMemcpyHostToDevice));
-    HIPCHK(hipMalloc((void**)&c->d_chans, sizeof(lc3d_dchan) * c->ncs));
-    HIPCHK(hipMalloc((void**)&c->d_state, sizeof(float) * DST_WORDS * (size_t)c->ncs));
+    HIPCHK_OR(hipMalloc((void**)&c->d_plan, sizeof(lc3d_plan)), lc3hip_dec_destroy(c));
+    HIPCHK_OR(hipMemcpy(c->d_plan, plan, sizeof(lc3d_plan), hipMemcpyHostToDevice), lc3hip_dec_destroy(c));
+    HIPCHK_OR(hipMalloc((void**)&c->d_chans, sizeof(lc3d_dchan) * c->ncs), lc3hip_dec_destroy(c));
+    HIPCHK_OR(hipMalloc((void**)&c->d_state, sizeof(float) * DST_WORDS * (size_t)c->ncs), lc3hip_dec_destroy(c));
     {   /* initial state: zeros; ltpf_mem_beta_idx = -1, cum_alpha = 1, PLC seed 24607 (R/setup_dec_lc3.c:170-183) */
         float* h = (float*)calloc((size_t)DST_WORDS * c->ncs, sizeof(float));
-        if (!h) return 1;
+        if (!h) { lc3hip_dec_destroy(c); return 1; }
         for (int i = 0; i < c->ncs; i++) {
             int* sc = (int*)(h + (size_t)i * DST_WORDS + DST_SCAL);
             sc[DS_BETA_IDX] = -1; ((float*)sc)[DS_CUM_ALPHA] = 1.0f; sc[DS_PLC_SEED] = 24607;
         }
         hipError_t e = hipMemcpy(c->d_state, h, sizeof(float) * DST_WORDS * (size_t)c->ncs, hipMemcpyHostToDevice);
         free(h);
-        HIPCHK(e);
+        HIPCHK_OR(e, lc3hip_dec_destroy(c));
     }
-    HIPCHK(hipStreamCreate(&c->stream));
-    HIPCHK(hipEventCreate(&c->ev0)); HIPCHK(hipEventCreate(&c->ev1));
+    HIPCHK_OR(hipStreamCreate(&c->stream), lc3hip_dec_destroy(c));
+    HIPCHK_OR(hipEventCreate(&c->ev0), lc3hip_dec_destroy(c)); HIPCHK_OR(hipEventCreate(&c->ev1), lc3hip_dec_destroy(c));
     *out_ctx = c;
     return 0;
 }
@@ -2843,8 +2979,13 @@ extern "C" int lc3hip_dec_upload_chans(void* ctx, const lc3d_dchan* chans, int f
 {
     lc3hip_dctx* c = (lc3hip_dctx*)ctx;
     HIPCHK(hipSetDevice(c->device));
+    if (c->last_stream) { HIPCHK(hipStreamSynchronize(c->last_stream)); c->last_stream = nullptr; }
     HIPCHK(hipMemcpy(c->d_chans + first, chans, sizeof(lc3d_dchan) * count, hipMemcpyHostToDevice));
-    for (int i = 0; i < count; i++) if (chans[i].nbytes > c->max_nbytes) c->max_nbytes = chans[i].nbytes;
+    /* the largest frame of the batch selects the parse kernel's staging: keep it exact when sizes shrink again */
+    if (!c->h_nbytes) { c->h_nbytes = (int*)calloc((size_t)c->ncs, sizeof(int)); if (!c->h_nbytes) return 1; }
+    for (int i = 0; i < count; i++) c->h_nbytes[first + i] = chans[i].nbytes;
+    c->max_nbytes = 0;
+    for (int i = 0; i < c->ncs; i++) if (c->h_nbytes[i] > c->max_nbytes) c->max_nbytes = c->h_nbytes[i];
     return 0;
 }
 extern "C" int lc3hip_dec_decode(void* ctx, const void* frames, int frames_on_device, int in_stride, const uint8_t* bfi_host, int n_frames,
@@ -2923,6 +3064,7 @@ extern "C" int lc3hip_dec_decode(void* ctx, const void* frames, int frames_on_de
         hipLaunchKernelGGL(lc3_dec_synth_kernel, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, c->d_rec, c->d_ws, c->d_ov, n_frames, dpcm, bps, c->ncs, dst, dtr);
     }
     HIPCHK(hipGetLastError());
+    c->last_stream = s;
     HIPCHK(hipEventRecord(c->ev1, s));
     if (!pcm_on_device) HIPCHK(hipMemcpyAsync(pcm, dpcm, pcm_bytes, hipMemcpyDeviceToHost, s));
     if (trace_host) HIPCHK(hipMemcpyAsync(trace_host, dtr, sizeof(lc3d_dec_trace) * (size_t)c->ncs * n_frames, hipMemcpyDeviceToHost, s));
@@ -2939,8 +3081,13 @@ extern "C" int lc3hip_dec_destroy(void* ctx)
     lc3hip_dctx* c = (lc3hip_dctx*)ctx;
     if (!c) return 0;
     hipSetDevice(c->device);
-    hipFree(c->d_plan); hipFree(c->d_chans); hipFree(c->d_state); hipFree(c->d_in); hipFree(c->d_pcm); hipFree(c->d_bfi); hipFree(c->d_trace); hipFree(c->d_status); hipFree(c->d_rec); hipFree(c->d_ws); hipFree(c->d_ov);
-    hipStreamDestroy(c->stream); hipEventDestroy(c->ev0); hipEventDestroy(c->ev1);
+    hipDeviceSynchronize();
+    void* bufs[] = {c->d_plan, c->d_chans, c->d_state, c->d_in, c->d_pcm, c->d_bfi, c->d_trace, c->d_status, c->d_rec, c->d_ws, c->d_ov};
+    for (void* p : bufs) if (p) hipFree(p);
+    if (c->stream) hipStreamDestroy(c->stream);
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    free(c->h_nbytes);
     free(c);
     return 0;
 }

@@ -68,6 +68,10 @@ typedef struct {
 #define LC3D_STATE_WORDS(mc) ((mc) + 660)
 #define LC3D_STATE_WORDS_MAX LC3D_STATE_WORDS(LC3D_MEMCAP_BIG)
 
+/* per channel-frame status bits of the encoder: conditions the reference only asserts on (SURVEY 5 "failure detection") */
+#define LC3D_ENC_ST_BIT_BUDGET  1        /* side information + range-coder bits exceed the frame (R/ari_codec.c:777) */
+#define LC3D_ENC_ST_QUANT_RANGE 2        /* a quantised line outside int16 without the high-resolution mode (R/quantize_spec.c:50) */
+
 /* ---- decoder (lc3_dec_kernels.inc) ---- */
 #define DEC_LY 864                       /* LTPF output history: ceil(228 * 48000 / 12800) + 6 = 861 */
 #define DEC_LX 16                        /* LTPF input history (tilt filter length - 1 <= 10) */

@@ -33,7 +33,9 @@ LC3_Error lc3plus_enc_batch_set_bandwidth(lc3plus_batch* batch, int stream, int 
 /* Advances every stream by n_frames.
  *   pcm : [n_streams][n_frames][channels][input_samples] samples, int16_t (bitdepth 16) or int32_t (24/32)
  *   out : [n_streams][n_frames][out_stride] bytes; frame payload = num_bytes(stream) bytes, rest untouched
- *   *_on_device : 0 = host pointer (copied with hipMemcpyAsync), 1 = device pointer used in place
+ *   *_on_device : 0 = host pointer, 1 = device pointer used in place.  With BOTH on the host the call is cut into runs of frames
+ *                 whose H2D copy, kernels and D2H copy overlap on three HIP streams; pinned caller memory (hipHostMalloc /
+ *                 hipHostRegister) is copied in place, pageable memory is staged through the batch's pinned buffers
  *   hip_stream  : hipStream_t to enqueue on (NULL = the batch's own stream); the call returns after the
  *                 work is complete when sync != 0, otherwise right after enqueueing.                  */
 LC3_Error lc3plus_enc_batch_encode(lc3plus_batch* batch, const void* pcm, int pcm_on_device, int bitdepth,
@@ -42,6 +44,12 @@ LC3_Error lc3plus_enc_batch_encode(lc3plus_batch* batch, const void* pcm, int pc
 
 /* Kernel-only timing of the last encode() call in milliseconds (HIP events on the launch stream). */
 float lc3plus_enc_batch_last_kernel_ms(lc3plus_batch* batch);
+
+/* Per channel-frame status of the last encode() call (device-pointer calls and host calls short enough for one run): conditions the
+ * reference only asserts on - bit 0: side information + range-coder bits exceed the frame (R/ari_codec.c:777), bit 1: a quantised
+ * line outside int16 outside the high-resolution mode (R/quantize_spec.c:50).  status: host array [n_streams * channels][n_frames];
+ * returns the number of entries written (0 before the first call), negative on error.  Waits for the call to finish. */
+int lc3plus_enc_batch_last_status(lc3plus_batch* batch, uint8_t* status, int max_entries);
 
 /* ---- batched decoder: n_streams independent decoder instances, one wavefront per channel-stream; same
  * conventions as the encoder batch.  num_bytes[n_streams] = bytes per stream-frame (all channels; may be NULL

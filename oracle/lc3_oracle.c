@@ -1312,26 +1312,34 @@ int lc3o_enc_frame(lc3o_enc* e, void** input, int bitdepth, uint8_t* out, int* n
     return LC3O_OK;
 }
 
-int lc3o_encode_batch16(int samplerate, float frame_ms, int hrmode, int B, int T, const int* bitrate,
-                        const int16_t* pcm, uint8_t* out, int stride)
+/* B independent streams of `channels` channels each, T frames, PCM [B][T][channels][N] int16 -> out [B][T][stride] (the channel
+ * payloads of a frame concatenated, R/enc_lc3_fl.c:167-171).  Test-side convenience: one C call instead of B*T ctypes calls. */
+int lc3o_encode_batch16_ch(int samplerate, float frame_ms, int hrmode, int channels, int B, int T, const int* bitrate,
+                           const int16_t* pcm, uint8_t* out, int stride)
 {
     lc3o_enc* e = (lc3o_enc*)malloc(sizeof *e);
-    int rc = LC3O_OK;
+    int rc = e ? LC3O_OK : LC3O_ERROR;
     for (int b = 0; b < B && rc == LC3O_OK; b++) {
-        rc = lc3o_enc_init(e, samplerate, 1);
+        rc = lc3o_enc_init(e, samplerate, channels);
         if (!rc) rc = lc3o_enc_set_frame_ms(e, frame_ms);
         if (!rc) rc = lc3o_enc_set_hrmode(e, hrmode);
         if (!rc) rc = lc3o_enc_set_bitrate(e, bitrate[b]);
         if (rc) break;
         const int N = e->N;
         for (int t = 0; t < T && !rc; t++) {
-            void* in[1] = {(void*)(pcm + ((size_t)b * T + t) * N)};
+            void* in[2];
+            for (int c = 0; c < channels; c++) in[c] = (void*)(pcm + (((size_t)b * T + t) * channels + c) * N);
             int nb = 0;
             rc = lc3o_enc_frame(e, in, 16, out + ((size_t)b * T + t) * stride, &nb);
         }
     }
     free(e);
     return rc;
+}
+int lc3o_encode_batch16(int samplerate, float frame_ms, int hrmode, int B, int T, const int* bitrate,
+                        const int16_t* pcm, uint8_t* out, int stride)
+{
+    return lc3o_encode_batch16_ch(samplerate, frame_ms, hrmode, 1, B, T, bitrate, pcm, out, stride);
 }
 
 /* test hook: the restated forward DFT on its own (tests/test_oracle_vs_ref.py pins it against the reference's LC3_iisfft_apply) */

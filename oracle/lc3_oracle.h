@@ -90,6 +90,8 @@ int  lc3o_dec_set_hrmode(lc3o_dec* d, int hrmode);
 int  lc3o_dec_get_output_samples(const lc3o_dec* d);
 int  lc3o_dec_frame(lc3o_dec* d, const uint8_t* input, int num_bytes, void** output, int bps, int bfi_ext);   /* 0, LC3O_DECODE_ERROR (concealed) or an error */
 int  lc3o_dft(float* x, int n);      /* test hook: forward complex DFT of length n in place (interleaved re, im); 0 = no kernel */
+int  lc3o_encode_batch16_ch(int samplerate, float frame_ms, int hrmode, int channels, int B, int T, const int* bitrate,
+                            const int16_t* pcm, uint8_t* out, int stride);
 int  lc3o_encode_batch16(int samplerate, float frame_ms, int hrmode, int B, int T, const int* bitrate,
                          const int16_t* pcm, uint8_t* out, int stride);
 

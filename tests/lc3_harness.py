@@ -316,3 +316,65 @@ def oracle_decode_streams(frames, nbytes, bfi, fs, frame_ms, hrmode, channels, b
             out[b, t] = pcm
             status[b, t] = rc == 2
     return out, status
+
+
+# ---------------------------------------------------------------------------------------------
+# spectral-distance fallback of the conformance procedure (E/conformance/lc3_conformance.py:126-129,572-582):
+# decode both bitstreams with the compiled reference decoder, compare the PCM with the ETSI `mld` tool
+# ---------------------------------------------------------------------------------------------
+MLD_TOOL = os.path.join(ORACLE_DIR, "_ref", "mld")
+MLD_THRESHOLD = 4.0     # DEFAULTS_TEST['*_mld_threshold'], lc3_conformance.py:127
+
+
+def _write_wav16(path, pcm_planar, fs):
+    import wave
+    w = wave.open(str(path), "wb")
+    w.setnchannels(pcm_planar.shape[0]); w.setsampwidth(2); w.setframerate(fs)
+    w.writeframes(np.ascontiguousarray(pcm_planar.T).astype("<i2").tobytes())
+    w.close()
+
+
+def ref_decode_stream(frames, fs, frame_ms, hrmode, channels=1):
+    """[T, nbytes] uint8 -> [channels, T*N] int16 through the compiled ETSI decoder (oracle/_ref)."""
+    d = RefDecoder(fs, channels, frame_ms, hrmode)
+    out = [d.decode(f)[1] for f in frames]
+    return np.concatenate(out, axis=1)
+
+
+def mld_between(frames_a, frames_b, fs, frame_ms, hrmode, channels=1, tmpdir=None):
+    """Maximum loudness difference (ETSI mld tool) between two bitstreams of one stream, both decoded by the reference
+    decoder.  The tool works at 48 kHz (the conformance script resamples); other rates are zero-order-held to 48 kHz
+    for 8/16/24 kHz and passed as they are otherwise (a relative check, same treatment on both sides)."""
+    import re
+    import tempfile
+    td = tmpdir or tempfile.mkdtemp(prefix="mld_")
+    paths = []
+    for tag, fr in (("a", frames_a), ("b", frames_b)):
+        pcm = ref_decode_stream(fr, fs, frame_ms, hrmode, channels)
+        if 48000 % fs == 0 and fs != 48000:
+            pcm = np.repeat(pcm, 48000 // fs, axis=1)
+        p = os.path.join(str(td), "mld_%s.wav" % tag)
+        _write_wav16(p, pcm, 48000)
+        paths.append(p)
+    out = subprocess.run([MLD_TOOL, "-d", paths[0], paths[1]], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True).stdout
+    m = re.search(r"maximum loudness difference:\s*(\S+)", out)
+    if not m:
+        raise RuntimeError("mld tool output not understood: %r" % out[-400:])
+    return float(m.group(1))
+
+
+def compare_frames(got, want_list, fs, frame_ms, hrmode, channels=1):
+    """got [B, T, stride], want_list[b] [T, nbytes_b].  Returns (differing frames, total, worst MLD over the streams that
+    differ or None).  The gates assert the first number against the committed count (0); the MLD says whether a
+    difference would still be inside the conformance tolerance (<= MLD_THRESHOLD) or is a real defect."""
+    diff = tot = 0
+    worst = None
+    for b, w in enumerate(want_list):
+        eq = (got[b, :, :w.shape[1]] == w).all(axis=1)
+        tot += eq.size
+        if not eq.all():
+            diff += int((~eq).sum())
+            if have_ref() and os.path.exists(MLD_TOOL):
+                v = mld_between(got[b, :, :w.shape[1]], w, fs, frame_ms, hrmode, channels)
+                worst = v if worst is None else max(worst, v)
+    return diff, tot, worst

@@ -62,6 +62,25 @@ def test_vs_oracle(fs, ms, hr, rates):
     assert len(bad) == 0, ("first differing (stream, frame)", bad[:4].tolist())
 
 
+@pytest.mark.parametrize("fs,ms,br,nbytes", [(48000, 10.0, 80000, 100), (48000, 10.0, 96000, 120), (48000, 10.0, 102400, 128),
+                                             (32000, 10.0, 96000, 120), (48000, 10.0, 104000, 130), (48000, 10.0, 64000, 80)])
+def test_uniform_size_batches_lds_parse_path(fs, ms, br, nbytes):
+    """lc3_dec_parse_kernel stages frames of up to 128 bytes in LDS and the switch is per batch: batches whose streams ALL have
+    the same size, at 10 ms frames of 81 ... 128 bytes (the longest symbol lists that path sees), the first size above it (global
+    variant) and the metric's 80 bytes; lost and corrupt frames included, two launches.  R/ari_codec.c:204-509."""
+    B, T = 64, 26
+    frames, nb, bfi = make_dec_case(fs, ms, 0, 1, [br] * B, T, seed=nbytes)
+    assert set(nb) == {nbytes}
+    d = _amd().DecBatch(B, fs, 1, ms, 0, nb, device=0)
+    a, sa = d.decode(frames[:, :11], bfi[:, :11])
+    b, sb = d.decode(frames[:, 11:], bfi[:, 11:])
+    got, status = np.concatenate([a, b], axis=1), np.concatenate([sa, sb], axis=1)
+    want, wstatus = oracle_decode_streams(frames, nb, bfi, fs, ms, 0, 1)
+    assert (status == wstatus).all()
+    bad = np.argwhere((got != want).any(axis=(2, 3)))
+    assert len(bad) == 0, ("first differing (stream, frame)", bad[:4].tolist())
+
+
 def test_golden_reference_decoder_output():
     """tests/golden/d1_decoder_operating_points.npz: frames damaged on purpose and the PCM / status the unmodified ETSI decoder
     produced from them (tests/golden/make_golden_dec.py)."""

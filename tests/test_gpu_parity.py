@@ -2,15 +2,19 @@
 against (1) the committed golden vectors generated from the unmodified ETSI reference and (2) the CPU oracle on the
 same seeded inputs.
 
-Tolerance (stated, SURVEY 8c / BASELINE north_star): integer stages are bit-exact by construction; because the
-reference's run-time libm calls (log2f/log10f/powf) are evaluated on the device as (float)f((double)x), a rare
-decision may flip, so the gate is >= 99 % byte-identical frames against the glibc-math reference vectors and
-100 % against the oracle built with the same math (oracle/liblc3_oracle_pm.so)."""
+Tolerance (stated, SURVEY 8c / BASELINE north_star): integer stages are bit-exact by construction.  The reference's
+run-time libm calls (log2f/log10f/powf) are evaluated on the device as (float)f((double)x), so against the glibc-math
+reference vectors a decision could in principle flip; the conformance procedure's tolerance for that is a maximum
+loudness difference of 4 between the two decoded signals (E/conformance/lc3_conformance.py:127).  Observed and
+therefore gated: ZERO differing frames against the reference vectors and against the oracle built with the device's
+math (oracle/liblc3_oracle_pm.so).  Should a frame ever differ, compare_frames() decodes both bitstreams with the
+compiled reference decoder and reports the MLD next to the count, so that the failure says whether it is a boundary
+flip (MLD <= 4) or a defect."""
 import os
 import numpy as np
 import pytest
 
-from lc3_harness import Oracle, oracle_encode_streams, synth_pcm
+from lc3_harness import Oracle, oracle_encode_streams, synth_pcm, compare_frames, MLD_THRESHOLD
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -38,8 +42,8 @@ def test_golden_mono(name):
     b = _amd().Batch(pcm.shape[0], int(g["fs"]), 1, float(g["frame_ms"]), int(g["hrmode"]), rates, device=0)
     got = b.encode(pcm)
     nb = g["nbytes"] if "nbytes" in g else [g["frames"].shape[2]] * pcm.shape[0]
-    same, tot = _frames_equal(got, [g["frames"][i][:, :nb[i]] for i in range(pcm.shape[0])])
-    assert same >= 0.99 * tot, (name, same, tot)
+    diff, tot, mld = compare_frames(got, [g["frames"][i][:, :nb[i]] for i in range(pcm.shape[0])], int(g["fs"]), float(g["frame_ms"]), int(g["hrmode"]))
+    assert diff == 0, (name, diff, tot, "worst MLD of the differing streams", mld)
 
 
 def test_golden_stereo():
@@ -47,8 +51,8 @@ def test_golden_stereo():
     pcm = np.ascontiguousarray(g["pcm"].transpose(0, 2, 1, 3))      # [pair, T, ch, N]
     b = _amd().Batch(pcm.shape[0], 48000, 2, 10.0, 0, [128000] * pcm.shape[0], device=0)
     got = b.encode(pcm)
-    eq = (got == g["frames"]).all(axis=2)
-    assert eq.mean() >= 0.99, eq.mean()
+    diff, tot, mld = compare_frames(got, list(g["frames"]), 48000, 10.0, 0, channels=2)
+    assert diff == 0, (diff, tot, "worst MLD of the differing streams", mld)
 
 
 @pytest.mark.parametrize("fs,ms,hr,N,rates", [
@@ -197,7 +201,7 @@ def test_cli_front_end_writes_the_reference_container(tmp_path, channels, bits, 
         assert len(ref) == len(got) and ref[:20] == got[:20]
         fr = 2 + o.nbytes
         same = sum(ref[20 + i * fr:20 + (i + 1) * fr] == got[20 + i * fr:20 + (i + 1) * fr] for i in range(38))
-        assert same >= 37, same
+        assert same == 38, same
 
 
 def test_cli_switching_files(tmp_path):
@@ -232,7 +236,7 @@ def test_cli_switching_files(tmp_path):
         subprocess.check_call([ref_cli, "-E", "-q", "-swf", str(swf), "-bandwidth", str(bwf), str(wav), str(theirs), "64000"], stdout=subprocess.DEVNULL)
         ref = open(theirs, "rb").read()
         assert len(ref) == len(got) and ref[:20] == got[:20]
-        assert sum(a != b for a, b in zip(ref, got)) <= 2 * 80      # at most a couple of frames may differ at the libm boundary
+        assert ref == got
 
 
 def _oracle_batch(pcm, fs, ms, hr, rates, stride):
@@ -283,16 +287,17 @@ def test_soak_every_operating_point():
 def test_golden_other_operating_points():
     """the reference's own vectors (tests/golden/c6, generated by make_golden.py) for every family outside 48 kHz / 10 ms"""
     g = np.load(os.path.join(G, "c6_other_operating_points.npz"))
-    tot = same = 0
+    tot = 0
     for tag in g["tags"]:
         tag = str(tag)
         fs, dms, hr, N = (int(v) for v in g[tag + "_cfg"])
         rates, pcm, frames, nbytes = g[tag + "_rates"], g[tag + "_pcm"], g[tag + "_frames"], g[tag + "_nbytes"]
         b = _amd().Batch(len(rates), fs, 1, dms / 10.0, hr, [int(r) for r in rates], device=0)
         got = b.encode(pcm)
-        s, t = _frames_equal(got, [frames[i][:, :nbytes[i]] for i in range(len(rates))])
-        tot += t; same += s
-    assert same >= 0.99 * tot, (same, tot)
+        d, t, mld = compare_frames(got, [frames[i][:, :nbytes[i]] for i in range(len(rates))], fs, dms / 10.0, hr)
+        assert d == 0, (tag, d, t, "worst MLD of the differing streams", mld)
+        tot += t
+    assert tot > 0
 
 
 @pytest.mark.parametrize("fs,ms,hr,br", [(16000, 10.0, 0, 32000), (8000, 2.5, 0, 64000), (32000, 10.0, 0, 64000), (96000, 10.0, 1, 256000)])
@@ -304,3 +309,125 @@ def test_single_stream_api_other_geometries(fs, ms, hr, br):
     o = Oracle(fs, 1, ms, hr, br, portable_math=True)
     for t in range(10):
         assert (e.encode(pcm[:, t]) == o.encode(pcm[:, t])).all(), t
+
+
+def _oracle_batch_ch(pcm, fs, ms, hr, channels, rates, stride):
+    """[B, T, channels, N] int16 through the oracle's C batch entry (device math) -> [B, T, stride] uint8."""
+    import ctypes as C
+    from lc3_harness import ORACLE_DIR
+    L = C.CDLL(os.path.join(ORACLE_DIR, "liblc3_oracle_pm.so"))
+    L.lc3o_encode_batch16_ch.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    B, T = pcm.shape[:2]
+    out = np.zeros((B, T, stride), np.uint8)
+    br = np.asarray(rates, np.int32)
+    pcm = np.ascontiguousarray(pcm)
+    assert L.lc3o_encode_batch16_ch(fs, ms, hr, channels, B, T, br.ctypes.data, pcm.ctypes.data, out.ctypes.data, stride) == 0
+    return out
+
+
+@pytest.mark.parametrize("fs,ms,br,nbytes", [
+    (48000, 10.0, 80000, 100), (48000, 10.0, 96000, 120), (48000, 10.0, 100000, 125), (48000, 10.0, 102400, 128),
+    (32000, 10.0, 96000, 120), (48000, 10.0, 104000, 130), (48000, 10.0, 64000, 80), (48000, 5.0, 192000, 120),
+])
+def test_uniform_size_batches_through_the_pack_kernel(fs, ms, br, nbytes):
+    """Batches in which EVERY stream has the same frame size, at the sizes round 1 never compared on the two-kernel path: 10 ms
+    frames of 81 ... 128 bytes (48 kHz 80 / 96 / 100 kbps, 32 kHz 96 kbps: attack detector on, LTPF off, 200 tuples, the longest symbol
+    and LSB lists that fit 128 bytes) and the first sizes above.  Two launches; vs the oracle with the device's math.
+    (R/enc_entropy.c:13-88, R/ari_codec.c:673-800)"""
+    B, T = 128, 24
+    N = int(fs * ms / 1000)
+    pcm = synth_pcm(B, T, N, fs, seed=4242)
+    b = _amd().Batch(B, fs, 1, ms, 0, [br] * B, device=0)
+    assert b.num_bytes(0) == nbytes
+    got = np.concatenate([b.encode(pcm[:, :T // 2]), b.encode(pcm[:, T // 2:])], axis=1)
+    want = _oracle_batch(pcm, fs, ms, 0, [br] * B, b.stride)
+    bad = [(i, t) for i in range(B) for t in range(T) if (got[i, t, :nbytes] != want[i, t, :nbytes]).any()]
+    assert not bad, (len(bad), bad[:8])
+
+
+def test_fused_writer_still_matches(monkeypatch):
+    """The wave-parallel bitstream writer inside lc3_encode_kernel (st_bitstream) now only runs for traced / diagnostic launches
+    (LC3PLUS_ENC_FUSED=1); it has to stay identical to the pack kernel and the oracle."""
+    monkeypatch.setenv("LC3PLUS_ENC_FUSED", "1")
+    B, T = 48, 16
+    rates = [RATES[i % len(RATES)] for i in range(B)]
+    pcm = synth_pcm(B, T, 480, 48000, seed=515)
+    b = _amd().Batch(B, 48000, 1, 10.0, 0, rates, device=0)
+    got = b.encode(pcm)
+    monkeypatch.delenv("LC3PLUS_ENC_FUSED")
+    b2 = _amd().Batch(B, 48000, 1, 10.0, 0, rates, device=0)
+    got2 = b2.encode(pcm)
+    want = _oracle_batch(pcm, 48000, 10.0, 0, rates, b.stride)
+    assert (got == want).all() and (got2 == want).all()
+
+
+@pytest.mark.parametrize("B,T,rates", [(1024, 16, [128000]), (96, 24, [64000, 128000, 256000, 61600, 32000, 640000])])
+def test_large_stereo_sweep_vs_oracle(B, T, rates):
+    """BASELINE configs[2]: stereo streams, 128 kbps per pair (80 bytes per channel) - 1 024 pairs x 16 frames =
+    32 768 channel-frames in one batch, the shape the 8-GPU run shards; second case: other stereo rates including an odd per-channel
+    split (61.6 kbps -> 77 bytes: 39 + 38, unaligned second payload) and the largest frames (400 bytes per channel)."""
+    br = [rates[i % len(rates)] for i in range(B)]
+    pcm = synth_pcm(B * 2, T, 480, 48000, seed=2027).reshape(B, 2, T, 480).transpose(0, 2, 1, 3)
+    pcm = np.ascontiguousarray(pcm)
+    b = _amd().Batch(B, 48000, 2, 10.0, 0, br, device=0)
+    got = np.concatenate([b.encode(pcm[:, :T // 2]), b.encode(pcm[:, T // 2:])], axis=1)
+    want = _oracle_batch_ch(pcm, 48000, 10.0, 0, 2, br, b.stride)
+    nb = np.array([b.num_bytes(i) for i in range(B)])
+    bad = [(i, t) for i in range(B) for t in range(T) if (got[i, t, :nb[i]] != want[i, t, :nb[i]]).any()]
+    assert not bad, (len(bad), bad[:8])
+
+
+def test_mld_fallback_machinery():
+    """The spectral-distance fallback itself (north_star: 'within a stated spectral-distance tolerance'): GPU
+    bitstreams and the reference's golden bitstreams, both decoded by the compiled reference decoder, through the ETSI mld tool:
+    0 for identical streams, and the tool is alive (a 32 kbps encode of the same PCM is further away than the threshold)."""
+    from lc3_harness import have_ref, mld_between, MLD_TOOL
+    if not (have_ref() and os.path.exists(MLD_TOOL)):
+        pytest.skip("oracle/_ref (compiled reference decoder + mld) did not travel with this snapshot")
+    g = np.load(os.path.join(G, "c1_48k_10ms_64k.npz"))
+    pcm = g["pcm"][:2]
+    b = _amd().Batch(2, 48000, 1, 10.0, 0, [64000, 32000], device=0)
+    got = b.encode(pcm)
+    assert mld_between(got[0, :, :80], g["frames"][0][:, :80], 48000, 10.0, 0) <= MLD_THRESHOLD
+    assert mld_between(got[0, :, :80], g["frames"][0][:, :80], 48000, 10.0, 0) == 0.0
+    b3 = _amd().Batch(1, 48000, 1, 10.0, 0, [32000], device=0)
+    low = b3.encode(pcm[:1])
+    assert mld_between(low[0, :, :40], g["frames"][0][:, :80], 48000, 10.0, 0) > 0.5
+
+
+def test_reference_cli_relinked_against_this_library(tmp_path):
+    """SURVEY 8b 'Who calls it': the reference's own CLI (R/codec_exe.c, unmodified, compiled against the reference's headers by
+    `make relink`) with every codec object replaced by liblc3plus_hip.so.  -E and -D files against the all-reference build
+    (oracle/_ref/LC3plus), including a rate-switching file in verbose mode: the CLI reads encoder->bitrate straight out of the
+    struct (R/codec_exe.c:298-299), so the printed rates prove the field offsets (R/setup_enc_lc3.h:65-104)."""
+    import subprocess
+    from lc3_harness import ORACLE_DIR
+    ours, theirs = os.path.join(ORACLE_DIR, "_ref", "LC3plus_hip"), os.path.join(ORACLE_DIR, "_ref", "LC3plus")
+    if not (os.path.exists(ours) and os.path.exists(theirs)):
+        pytest.skip("oracle/_ref/LC3plus_hip (make relink) did not travel with this snapshot")
+    for channels, bitrate in ((1, 64000), (2, 128000)):
+        nsamp = 480 * 30 + 77
+        pcm = synth_pcm(channels, 31, 480, 48000, seed=61).reshape(channels, -1)[:, :nsamp]
+        wav = tmp_path / ("in%d.wav" % channels)
+        _write_wav(wav, pcm.T.reshape(-1), 48000, channels, 16)
+        a, b = tmp_path / ("a%d.lc3plus" % channels), tmp_path / ("b%d.lc3plus" % channels)
+        subprocess.check_call([ours, "-E", "-q", str(wav), str(a), str(bitrate)], stdout=subprocess.DEVNULL)
+        subprocess.check_call([theirs, "-E", "-q", str(wav), str(b), str(bitrate)], stdout=subprocess.DEVNULL)
+        assert open(a, "rb").read() == open(b, "rb").read(), ("encode", channels)
+        wa, wb = tmp_path / ("a%d.wav" % channels), tmp_path / ("b%d.wav" % channels)
+        subprocess.check_call([ours, "-D", "-q", str(b), str(wa)], stdout=subprocess.DEVNULL)
+        subprocess.check_call([theirs, "-D", "-q", str(b), str(wb)], stdout=subprocess.DEVNULL)
+        assert open(wa, "rb").read() == open(wb, "rb").read(), ("decode", channels)
+    # verbose rate switching: the CLI prints encoder->bitrate before every change
+    rates = [64000] * 5 + [32000] * 5 + [96000] * 5
+    swf = tmp_path / "rates.bin"; np.array(rates, np.int64).tofile(swf)
+    wav = tmp_path / "in1.wav"
+    outs = []
+    for exe, name in ((ours, "sa"), (theirs, "sb")):
+        o = tmp_path / (name + ".lc3plus")
+        r = subprocess.run([exe, "-E", "-v", "-swf", str(swf), str(wav), str(o), "64000"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode == 0, r.stdout[-500:]
+        import re
+        outs.append((re.findall(r"Switching rate from \d+ to \d+", r.stdout), open(o, "rb").read()))
+    assert outs[0][0] == outs[1][0] and len(outs[0][0]) >= 2 and outs[0][0][0] == "Switching rate from 64000 to 32000", outs[0][0]
+    assert outs[0][1] == outs[1][1]

@@ -1,6 +1,8 @@
 """The N>1 path on CPU: two gloo ranks own disjoint stream blocks (audio_codec_amd.sharding), encode them independently with the
 CPU oracle standing in for the GPU step, and the union equals the unsharded result -- there is no exchange step to get wrong.
-Also exercises bench.py's barrier + max-over-ranks timing reduction."""
+The ranks are started by bench.py's own launcher (bench.launch_ranks: what `python bench.py --gpus N` does) and time their steps
+with bench.py's own protocol (bench.timed_steps: warm-up, barrier + sync on both sides, max over ranks), with the oracle as the
+step and gloo as the backend."""
 import hashlib
 import os
 import socket
@@ -17,22 +19,28 @@ WORKER = r'''
 import os, sys, hashlib, time
 sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
 import numpy as np, torch, torch.distributed as dist
+import bench                                                          # the repo's bench.py: its rank / timing code is what runs here
 from audio_codec_amd.sharding import stream_block
 from lc3_harness import synth_pcm, oracle_encode_streams
+rank, world, local = bench.rank_env()
 dist.init_process_group("gloo")
-rank, world = dist.get_rank(), dist.get_world_size()
+assert (rank, world) == (dist.get_rank(), dist.get_world_size())
 TOTAL, T = 10, 6
 first, last = stream_block(rank, world, TOTAL)
 pcm = synth_pcm(TOTAL, T, 480, 48000, seed=77)[first:last]          # every rank generates only what it owns
-dist.barrier(); t0 = time.perf_counter()
-frames = oracle_encode_streams(pcm, 48000, 10.0, 0, [64000] * (last - first))
-dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
-dist.barrier()
-dist.all_reduce(dt, op=dist.ReduceOp.MAX)                            # bench.py: max over ranks
+frames = []
+calls = [0]
+def step():
+    calls[0] += 1
+    frames[:] = oracle_encode_streams(pcm, 48000, 10.0, 0, [64000] * (last - first))
+    if rank == 1: time.sleep(0.05)                                    # the slower rank must set the reported time
+wall = bench.timed_steps(step, 2, 1, lambda: None, dist)
+assert calls[0] == 3
+own = torch.tensor([0.1 if rank == 1 else 0.0], dtype=torch.float64)
 digests = [None] * world
 dist.all_gather_object(digests, [hashlib.md5(f.tobytes()).hexdigest() for f in frames])
 if rank == 0:
-    print("DIGESTS", ",".join(d for per in digests for d in per), "MAXT", float(dt.item()) > 0)
+    print("DIGESTS", ",".join(d for per in digests for d in per), "MAXT", wall >= 0.1)
 dist.destroy_process_group()
 '''
 
@@ -55,9 +63,10 @@ def test_two_rank_gloo_matches_unsharded(tmp_path):
     from lc3_harness import oracle_encode_streams, synth_pcm
     script = tmp_path / "worker.py"
     script.write_text(WORKER % {"root": ROOT})
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                          "--master-port", str(port), str(script)], capture_output=True, text=True, timeout=300)
+    # bench.launch_ranks() is the code path of `python bench.py --gpus 2`; run it in a child so that its output can be captured
+    drv = tmp_path / "driver.py"
+    drv.write_text("import sys; sys.path.insert(0, %r); import bench; sys.exit(bench.launch_ranks(2, [], script=%r))\n" % (ROOT, str(script)))
+    out = subprocess.run([sys.executable, str(drv)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("DIGESTS")][0]
     got = line.split()[1].split(",")
@@ -65,3 +74,10 @@ def test_two_rank_gloo_matches_unsharded(tmp_path):
     want = [hashlib.md5(f.tobytes()).hexdigest() for f in oracle_encode_streams(pcm, 48000, 10.0, 0, [64000] * 10)]
     assert got == want
     assert line.split()[3] == "True"
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """`python bench.py --gpus 8` must not quietly report n_gpus: 1: without 8 visible devices it exits non-zero before touching the GPU."""
+    env = dict(os.environ); env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 3 and "device(s) visible" in out.stderr and not out.stdout.strip(), (out.returncode, out.stderr[-300:])
