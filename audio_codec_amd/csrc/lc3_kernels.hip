@@ -165,6 +165,13 @@ __device__ __forceinline__ int wave_incl_scan_i(int v, int lane)
 }
 /* reductions return the wave-uniform result (lane 63 of the scan) */
 __device__ __forceinline__ int wave_sum_i(int v) { return __builtin_amdgcn_readlane(wave_incl_scan_i(v, 0), 63); }
+/* float sum over the wave in DPP tree order (NOT the reference's serial order: only for values that are allowed to be approximate) */
+__device__ __forceinline__ float wave_sum_f_tree(float v)
+{
+    v += dpp_f<DPP_SHR1>(0.0f, v); v += dpp_f<DPP_SHR2>(0.0f, v); v += dpp_f<DPP_SHR4>(0.0f, v); v += dpp_f<DPP_SHR8>(0.0f, v);
+    v += dpp_f<DPP_BC15, 0xA>(0.0f, v); v += dpp_f<DPP_BC31, 0xC>(0.0f, v);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
 __device__ __forceinline__ float wave_max_f(float v)
 {
     v = fmaxf(v, dpp_f<DPP_SHR1>(v, v)); v = fmaxf(v, dpp_f<DPP_SHR2>(v, v)); v = fmaxf(v, dpp_f<DPP_SHR4>(v, v)); v = fmaxf(v, dpp_f<DPP_SHR8>(v, v));
@@ -1827,22 +1834,43 @@ STAGE void st_gain_estimate(const lc3d_plan* __restrict__ P, const lc3d_chan* __
         const float target = (float)((28.0 / 20.0) * (1.4) * (double)nbitsSQ);
         const float thr7 = PF(c_thr7_up), thr50 = PF(c_thr50_dn);
         const int offset0 = 255 + off;
-        /* 8-step bisection, evaluated speculatively: lanes 1..63 are the decision-tree nodes of the first six steps */
+        /* 8-step bisection R/estimate_global_gain.c:97-124.  A probe compares an ORDERED float sum of up to 240 non-negative terms with
+         * the target, so only the sign of (sum - target) is needed: every probe is first evaluated lane-parallel (one term per lane,
+         * the iszero latch = "no band above this one has left the quiet state" from a ballot, tree sum in float).  The serial float
+         * sum of n non-negative terms differs from the exact sum by at most n * 2^-24 * sum, the tree sum of rounded terms by at most
+         * (log2(n) + 3) * 2^-24 * sum: when the tree sum is further from the target than 4e-5 * sum + 1e-4 (> twice both bounds at
+         * n = 240) the reference's comparison is decided.  Otherwise (measured: well under 1 % of the probes) that probe is repeated with
+         * the reference's serial chain (gain_probe).  ~40 instructions per step instead of two 100-step double-precision chains. */
         int m = 0;
-        {
-            const int lvl = lane ? ilog2((unsigned)lane) : 0, p = lane - (1 << lvl);
-            const int cand = offset0 - (p << (8 - lvl)) - (128 >> lvl);
-            const unsigned long long addback = __ballot(gain_probe(thr7, thr50, en, gain_probe_len(thr7, ev, lane, nq, offset0 - 252), cand, target));
-            int node = 1;
-            for (int i = 0; i < 6; i++) { const int nb = ((addback >> node) & 1ull) ? 0 : 1; m += nb << (7 - i); node = 2 * node + nb; }
+        const float c_lo_f = (float)((2.7) * (28.0 / 20.0));
+        for (int i = 0; i < 8; i++) {
+            const int fac = 128 >> i, cand = offset0 - m - fac;
+            const float fc = (float)cand;
+            float tsum = 0; int top = -1;
+            bool lo_[NQL]; float tv[NQL];
+#pragma unroll
+            for (int h = NQL - 1; h >= 0; h--) {
+                const bool valid = lane + 64 * h < nq;
+                const float t = ev[h] - fc;
+                lo_[h] = !valid || t < thr7;
+                tv[h] = t > thr50 ? (t + t) - 70.0f : t;
+                const unsigned long long nz = __ballot(!lo_[h]);
+                if (nz && top < 0) top = 64 * h + 63 - (int)__clzll((long long)nz);
+            }
+#pragma unroll
+            for (int h = 0; h < NQL; h++) tsum += lo_[h] ? (lane + 64 * h < top ? c_lo_f : 0.0f) : tv[h];
+            const float S = wave_sum_f_tree(tsum);
+            bool addback;
+            if (top < 0) addback = false;                                         /* iszero stays set: never added back */
+            else {
+                const float margin = 4e-5f * S + 1e-4f;
+                if (S - margin > target) addback = true;
+                else if (S + margin < target) addback = false;
+                else addback = gain_probe(thr7, thr50, en, nq, cand, target);         /* too close to call: the reference's serial sum */
+            }
+            if (!addback) m += fac;
         }
         SUB(12);
-        {   /* last two steps: lane 0: step 6; lane 1: step 7 if step 6 added back; lane 2: step 7 otherwise */
-            const int cand = lane == 0 ? offset0 - m - 2 : lane == 1 ? offset0 - m - 1 : offset0 - m - 3;
-            const unsigned long long addback = __ballot(gain_probe(thr7, thr50, en, gain_probe_len(thr7, ev, lane, nq, offset0 - m - 3), cand, target));
-            if (addback & 1ull) { if (!(addback & 2ull)) m += 1; }
-            else { m += 2; if (!(addback & 4ull)) m += 1; }
-        }
         SUB(13);
         const int offset = offset0 - m;
         if ((float)offset < ind_min) mem_target = -1;
@@ -2020,9 +2048,27 @@ STAGE void st_noise_factor(const lc3d_plan* __restrict__ P, WaveLds& L, int lane
     }
     const int msplit = split ? sumz / nz : 0x7fffffff;
     float m1 = 0, m2 = 0; int j1 = 0;
+    /* The level index is round(8 - 16 * mean) clamped to 0..7, the mean an ORDERED float sum of up to ~400 non-negative terms: first a
+     * lane-parallel tree sum; the serial sum of n terms differs from it by less than (n + 10) * 2^-24 of the sum (see st_gain_estimate),
+     * so unless 8 - 16 * mean comes within that of a rounding boundary the index is decided without the serial chain. */
+    bool decided = false; float idx_fast = 0;
+    if (!split && nz > 0) {
+        float ts = 0;
+#pragma unroll
+        for (int c = 0; c < 8; c++) { const int k = first + 64 * c + lane; if ((zm[c] >> lane) & 1ull) ts += fabsf(L.A[k] / gg); }
+        const float S = wave_sum_f_tree(ts);
+        const float v = 8.0f - 16.0f * (S / (float)nz), d = 16.0f * (S / (float)nz) * 6e-5f + 2e-5f;
+        float a = (float)round((double)(v - d)), b = (float)round((double)(v + d));
+        a = a > 0 ? a : 0; a = a < 7 ? a : 7; b = b > 0 ? b : 0; b = b < 7 ? b : 7;
+        decided = a == b; idx_fast = a;
+    }
+    if (decided) {
+        if (lane == 0) L.isc[I_FACNS] = (int)idx_fast;
+        LSYNC();
+        SUB(32);
+        return;
+    }
     if (!split) {
-        /* common case: one serial sum over all zero lines.  They are compacted (in bin order) into LDS scratch three chunks
-         * at a time and summed with uniform-address reads. */
         float* lst = &L.sm[MAXN / 2 + 2];           /* >= 306 free words (16-byte aligned): the residual-bit area is not in use yet */
         j1 = nz;
 #pragma unroll
