@@ -2490,7 +2490,8 @@ KERNEL_NAME(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans
                   const void* __restrict__ pcm, int bitdepth, int T, uint8_t* __restrict__ out, int out_stride, int ncs,
                   lc3d_trace* __restrict__ trace, int* __restrict__ dump /* [cs][T][dstride] hand-over to lc3_enc_pack_kernel, or null: write the bytes here */, int dstride,
                   const float* __restrict__ y12 /* [cs][T][128] HP-filtered 12.8 kHz signal from the pre-kernels, or null: resample here */,
-                  uint8_t* __restrict__ status /* [cs][T] LC3D_ENC_ST_* bits (zeroed by the host), or null */)
+                  uint8_t* __restrict__ status /* [cs][dT] LC3D_ENC_ST_* bits (zeroed by the host), or null */,
+                  int dT, int dt0 /* the hand-over and the status rows hold dT frames per channel-stream; this launch's frame t is their frame dt0 + t */)
 {
     __shared__ WaveLds L;
     const int lane = threadIdx.x;
@@ -2629,7 +2630,7 @@ KERNEL_NAME(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans
         if (dump) {
             /* the bitstream of a frame depends on nothing but this: scalars, residual bits, quantised lines up to lastnz.  The
              * serial writer runs one frame per lane in lc3_enc_pack_kernel. */
-            int* r = dump + ((size_t)cs * T + t) * dstride;
+            int* r = dump + ((size_t)cs * dT + dt0 + t) * dstride;
             if (lane < 56) r[lane] = L.isc[lane];
             const int lastnz = uni(L.isc[I_LASTNZ]), nresw = uni(L.isc[I_LSB]) == 0 ? (uni(L.isc[I_NRES]) + 31) >> 5 : 0;
             for (int i = lane; i < nresw; i += WAVE) r[PK_RES + i] = (int)((const uint32_t*)RESB(L))[i];
@@ -2644,7 +2645,7 @@ KERNEL_NAME(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans
                     ovf |= q0 != (int)(int16_t)q0 || q1 != (int)(int16_t)q1;
                     r[PK_XQ + p] = (q0 & 0xFFFF) | (q1 << 16);
                 }
-                if (status && __ballot(ovf) && lane == 0) status[(size_t)cs * T + t] |= LC3D_ENC_ST_QUANT_RANGE;
+                if (status && __ballot(ovf) && lane == 0) status[(size_t)cs * dT + dt0 + t] |= LC3D_ENC_ST_QUANT_RANGE;
             }
             LSYNC();
             TICK(16);
@@ -2684,7 +2685,7 @@ KERNEL_NAME(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans
 extern "C" __global__ void lc3_encode_kernel_big(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans, float* __restrict__ state,
                                                  const void* __restrict__ pcm, int bitdepth, int T, uint8_t* __restrict__ out, int out_stride, int ncs,
                                                  lc3d_trace* __restrict__ trace, int* __restrict__ dump, int dstride, const float* __restrict__ y12,
-                                                 uint8_t* __restrict__ status);
+                                                 uint8_t* __restrict__ status, int dT, int dt0);
 #include "lc3_enc_pack.inc"
 #include "lc3_enc_pre.inc"
 struct lc3hip_ctx {
@@ -2695,8 +2696,8 @@ struct lc3hip_ctx {
     int* d_dump; size_t dump_cap; int hr, fused; float* d_y12; size_t y12_cap;
     uint8_t* d_status; size_t status_cap; int status_frames;      /* per channel-frame status bits of the last call (LC3D_ENC_ST_*) */
     /* host-pointer pipeline (lc3hip_encode_host): two chunk slots, each with device staging and (for pageable callers) pinned staging */
-    void* hp_dpcm[2]; uint8_t* hp_dout[2]; void* hp_pin_in[2]; uint8_t* hp_pin_out[2]; size_t hp_pcm_cap, hp_out_cap, hp_pin_in_cap, hp_pin_out_cap;
-    hipStream_t s_h2d, s_d2h; hipEvent_t ev_h2d[2], ev_k[2], ev_d2h[2];
+    void* hp_dpcm[2]; void* hp_pin_in[2]; size_t hp_pcm_cap, hp_pin_in_cap;
+    hipStream_t s_h2d; hipEvent_t ev_h2d[2], ev_k[2];
     hipStream_t stream, last_stream; hipEvent_t ev0, ev1; float last_ms;
 };
 
@@ -2755,8 +2756,11 @@ extern "C" int lc3hip_upload_chans(void* ctx, const lc3d_chan* chans, int first,
     return 0;
 }
 
-/* the kernels of one call on stream s: PCM and output both in device memory */
-static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frames, uint8_t* dout, int out_stride, hipStream_t s, lc3d_trace* dtr)
+/* the kernels of one call (or of one run of frames of a call) on stream s, PCM and output in device memory.  n_frames frames from
+ * dpcm [stream][n_frames][channel][N]; the hand-over records and status bytes are rows of dT frames per channel-stream in which this
+ * launch fills frames dt0 ... dt0 + n_frames - 1; with `pack` the bitstream writer then runs over all dT frames into dout [stream][dT][out_stride]. */
+static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frames, uint8_t* dout, int out_stride, hipStream_t s, lc3d_trace* dtr,
+                      int dT, int dt0, bool pack)
 {
     /* two kernels: lc3_encode_kernel (one wave per channel-stream, frames in order) leaves each frame's parameters and quantised
      * spectrum in a record; lc3_enc_pack_kernel (one channel-frame per lane, any frame size) writes the bytes.  With stage traces,
@@ -2764,7 +2768,7 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
     int* ddump = nullptr; int dstride = 0;
     if (!dtr && !c->fused) {
         dstride = PK_STRIDE(c->N, c->hr);
-        const size_t need = (size_t)c->ncs * n_frames * dstride;
+        const size_t need = (size_t)c->ncs * dT * dstride;
         if (c->dump_cap < need) { if (c->d_dump) HIPCHK(hipFree(c->d_dump)); c->d_dump = nullptr; c->dump_cap = 0; HIPCHK(hipMalloc((void**)&c->d_dump, need * sizeof(int))); c->dump_cap = need; }
         ddump = c->d_dump;
     }
@@ -2775,11 +2779,11 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
         if (c->y12_cap < need) { if (c->d_y12) HIPCHK(hipFree(c->d_y12)); c->d_y12 = nullptr; c->y12_cap = 0; HIPCHK(hipMalloc((void**)&c->d_y12, need * sizeof(float))); c->y12_cap = need; }
         dy12 = c->d_y12;
     }
-    {   /* per channel-frame status bits (LC3D_ENC_ST_*), cleared per call */
-        const size_t need = (size_t)c->ncs * n_frames;
+    if (dt0 == 0) {   /* per channel-frame status bits (LC3D_ENC_ST_*), cleared per call */
+        const size_t need = (size_t)c->ncs * dT;
         if (c->status_cap < need) { if (c->d_status) HIPCHK(hipFree(c->d_status)); c->d_status = nullptr; c->status_cap = 0; HIPCHK(hipMalloc((void**)&c->d_status, need)); c->status_cap = need; }
         HIPCHK(hipMemsetAsync(c->d_status, 0, need, s));
-        c->status_frames = n_frames;
+        c->status_frames = dT;
     }
     if (dy12) {
         const int mc = c->big ? LC3D_MEMCAP_BIG : LC3D_MEMCAP_STD;
@@ -2789,16 +2793,16 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
         HIPCHK(hipGetLastError());
     }
     if (c->big) hipLaunchKernelGGL(lc3_encode_kernel_big, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames,
-                                   dout, out_stride, c->ncs, dtr, ddump, dstride, dy12, c->d_status);
+                                   dout, out_stride, c->ncs, dtr, ddump, dstride, dy12, c->d_status, dT, dt0);
     else hipLaunchKernelGGL(lc3_encode_kernel, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames,
-                            dout, out_stride, c->ncs, dtr, ddump, dstride, dy12, c->d_status);
-    if (ddump) {
+                            dout, out_stride, c->ncs, dtr, ddump, dstride, dy12, c->d_status, dT, dt0);
+    if (ddump && pack) {
         HIPCHK(hipGetLastError());
         const int wpg = 4;
         const size_t per_wave = (size_t)PK_XBUF * WAVE * sizeof(unsigned);
-        const long long tasks = (long long)c->ncs * n_frames, per_wg = (long long)wpg * WAVE;
+        const long long tasks = (long long)c->ncs * dT, per_wg = (long long)wpg * WAVE;
         hipLaunchKernelGGL(lc3_enc_pack_kernel, dim3((unsigned)((tasks + per_wg - 1) / per_wg)), dim3(wpg * WAVE), per_wave * wpg, s, c->d_plan, c->d_chans, ddump, dstride,
-                           n_frames, c->ncs, dout, out_stride, c->d_status);
+                           dT, c->ncs, dout, out_stride, c->d_status);
     }
     HIPCHK(hipGetLastError());
     c->last_stream = s;
@@ -2812,46 +2816,41 @@ static bool host_ptr_is_pinned(const void* p)
     return a.type == hipMemoryTypeHost;
 }
 
-/* Host pointers on both sides (SURVEY 8d "wall-clock over the encode() call including H2D of PCM and D2H of bitstreams"): the call is
- * cut into runs of frames (all streams advance together, so every run fills the GPU like the whole call would; cutting by streams
- * would not); run k's PCM goes up on one stream while run k-1 is encoded on the launch stream and run k-2's frames come down on a
- * third.  PCM of a run is a strided block of the caller's [stream][frame][channel][N] array: a 2-D copy straight from / to the
- * caller's memory when that is pinned (hipHostMalloc / hipHostRegister), otherwise rows are staged through the library's own pinned
- * slots by the calling thread, which overlaps with the GPU work of the previous run.  State stays on the device between runs. */
+/* Host pointers on both sides (SURVEY 8d "wall-clock over the encode() call including H2D of PCM and D2H of bitstreams"): the PCM of a
+ * call is cut into runs of frames (all streams advance together, so every run fills the GPU like the whole call would; cutting by
+ * streams would not).  Run k+1 goes up on a copy stream while run k is encoded on the launch stream: PCM of a run is a strided block of
+ * the caller's [stream][frame][channel][N] array - a 2-D copy (SDMA) straight from the caller's memory when that is pinned
+ * (hipHostMalloc / hipHostRegister), otherwise rows are staged through the library's own pinned slots by the calling thread, which
+ * overlaps with the GPU work of the previous run.  The bitstream writer runs ONCE behind the last run over all frames of the call (one
+ * frame per lane makes it latency bound: per run it would cost as much as for the whole call), then the frames come down in one
+ * linear copy.  State stays on the device between runs.  The first run is short so that the kernels start early. */
 static int encode_host(lc3hip_ctx* c, const void* pcm, int bitdepth, int n_frames, void* out, int out_stride, hipStream_t s)
 {
     const size_t bps = bitdepth == 16 ? 2 : 4;
     const size_t fr_in = (size_t)c->channels * c->N * bps;                    /* bytes of one stream-frame of PCM */
-    const size_t pcm_bytes = (size_t)c->n_streams * n_frames * fr_in;
+    const size_t pcm_bytes = (size_t)c->n_streams * n_frames * fr_in, out_bytes = (size_t)c->n_streams * n_frames * out_stride;
     int K = (int)(pcm_bytes >> 25);                                           /* ~32 MB of PCM per run */
     if (K < 1) K = 1; if (K > 8) K = 8; if (K > n_frames) K = n_frames;
-    const int Tc = (n_frames + K - 1) / K;
-    const bool pin_in = host_ptr_is_pinned(pcm), pin_out = host_ptr_is_pinned(out);
-    const size_t cin = (size_t)c->n_streams * Tc * fr_in, cout = (size_t)c->n_streams * Tc * out_stride;
+    if (c->fused) K = 1;                                                      /* diagnostic single-kernel path: the first kernel addresses the output by its own frame count */
+    const int Tc = (n_frames + K - 1) / K, T0 = K > 1 ? (Tc + 1) / 2 : Tc;   /* first run: half a run */
+    const bool pin_in = host_ptr_is_pinned(pcm);
+    const size_t cin = (size_t)c->n_streams * Tc * fr_in;
     if (!c->s_h2d) {
-        HIPCHK(hipStreamCreateWithFlags(&c->s_h2d, hipStreamNonBlocking)); HIPCHK(hipStreamCreateWithFlags(&c->s_d2h, hipStreamNonBlocking));
-        for (int i = 0; i < 2; i++) { HIPCHK(hipEventCreateWithFlags(&c->ev_h2d[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_k[i], hipEventDisableTiming));
-                                      HIPCHK(hipEventCreateWithFlags(&c->ev_d2h[i], hipEventDisableTiming)); }
+        HIPCHK(hipStreamCreateWithFlags(&c->s_h2d, hipStreamNonBlocking));
+        for (int i = 0; i < 2; i++) { HIPCHK(hipEventCreateWithFlags(&c->ev_h2d[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_k[i], hipEventDisableTiming)); }
     }
     if (c->hp_pcm_cap < cin) { for (int i = 0; i < 2; i++) { if (c->hp_dpcm[i]) HIPCHK(hipFree(c->hp_dpcm[i])); c->hp_dpcm[i] = nullptr; } c->hp_pcm_cap = 0;
                                for (int i = 0; i < 2; i++) HIPCHK(hipMalloc(&c->hp_dpcm[i], cin)); c->hp_pcm_cap = cin; }
-    if (c->hp_out_cap < cout) { for (int i = 0; i < 2; i++) { if (c->hp_dout[i]) HIPCHK(hipFree(c->hp_dout[i])); c->hp_dout[i] = nullptr; } c->hp_out_cap = 0;
-                                for (int i = 0; i < 2; i++) HIPCHK(hipMalloc((void**)&c->hp_dout[i], cout)); c->hp_out_cap = cout; }
     if (!pin_in && c->hp_pin_in_cap < cin) { for (int i = 0; i < 2; i++) { if (c->hp_pin_in[i]) HIPCHK(hipHostFree(c->hp_pin_in[i])); c->hp_pin_in[i] = nullptr; } c->hp_pin_in_cap = 0;
                                              for (int i = 0; i < 2; i++) HIPCHK(hipHostMalloc(&c->hp_pin_in[i], cin, hipHostMallocDefault)); c->hp_pin_in_cap = cin; }
-    if (!pin_out && c->hp_pin_out_cap < cout) { for (int i = 0; i < 2; i++) { if (c->hp_pin_out[i]) HIPCHK(hipHostFree(c->hp_pin_out[i])); c->hp_pin_out[i] = nullptr; } c->hp_pin_out_cap = 0;
-                                                for (int i = 0; i < 2; i++) HIPCHK(hipHostMalloc((void**)&c->hp_pin_out[i], cout, hipHostMallocDefault)); c->hp_pin_out_cap = cout; }
-    const size_t in_pitch = (size_t)n_frames * fr_in, out_pitch = (size_t)n_frames * out_stride;
+    if (c->out_cap < out_bytes) { if (c->d_out) HIPCHK(hipFree(c->d_out)); c->d_out = nullptr; c->out_cap = 0; HIPCHK(hipMalloc((void**)&c->d_out, out_bytes)); c->out_cap = out_bytes; }
+    const size_t in_pitch = (size_t)n_frames * fr_in;
     HIPCHK(hipEventRecord(c->ev0, s));
-    int pend_t0[2] = {0, 0}, pend_tc[2] = {0, 0};                             /* runs whose frames still sit in a pinned output slot */
-    for (int k = 0, t0 = 0; t0 < n_frames; k++, t0 += Tc) {
-        const int i = k & 1, tc = n_frames - t0 < Tc ? n_frames - t0 : Tc;
-        const size_t w_in = (size_t)tc * fr_in, w_out = (size_t)tc * out_stride;
-        if (k >= 2) {                                                          /* slot i was used by run k - 2 */
-            HIPCHK(hipEventSynchronize(c->ev_d2h[i]));                         /* its kernels and copies are done: both staging slots are free */
-            if (!pin_out) for (int st = 0; st < c->n_streams; st++)
-                memcpy((uint8_t*)out + st * out_pitch + (size_t)pend_t0[i] * out_stride, c->hp_pin_out[i] + (size_t)st * pend_tc[i] * out_stride, (size_t)pend_tc[i] * out_stride);
-        }
+    HIPCHK(hipMemsetAsync(c->d_out, 0, out_bytes, s));
+    for (int k = 0, t0 = 0; t0 < n_frames; k++) {
+        const int i = k & 1, want = k == 0 ? T0 : Tc, tc = n_frames - t0 < want ? n_frames - t0 : want;
+        const size_t w_in = (size_t)tc * fr_in;
+        if (k >= 2) HIPCHK(hipEventSynchronize(c->ev_k[i]));                   /* run k - 2 has been encoded: its staging slot is free */
         const uint8_t* src = (const uint8_t*)pcm + (size_t)t0 * fr_in;
         if (pin_in) HIPCHK(hipMemcpy2DAsync(c->hp_dpcm[i], w_in, src, in_pitch, w_in, (size_t)c->n_streams, hipMemcpyHostToDevice, c->s_h2d));
         else {
@@ -2860,25 +2859,13 @@ static int encode_host(lc3hip_ctx* c, const void* pcm, int bitdepth, int n_frame
         }
         HIPCHK(hipEventRecord(c->ev_h2d[i], c->s_h2d));
         HIPCHK(hipStreamWaitEvent(s, c->ev_h2d[i], 0));
-        HIPCHK(hipMemsetAsync(c->hp_dout[i], 0, w_out * c->n_streams, s));
-        if (enc_launch(c, c->hp_dpcm[i], bitdepth, tc, c->hp_dout[i], out_stride, s, nullptr)) return 1;
+        if (enc_launch(c, c->hp_dpcm[i], bitdepth, tc, c->d_out, out_stride, s, nullptr, n_frames, t0, t0 + tc >= n_frames)) return 1;
         HIPCHK(hipEventRecord(c->ev_k[i], s));
-        HIPCHK(hipStreamWaitEvent(c->s_d2h, c->ev_k[i], 0));
-        if (pin_out) HIPCHK(hipMemcpy2DAsync((uint8_t*)out + (size_t)t0 * out_stride, out_pitch, c->hp_dout[i], w_out, w_out, (size_t)c->n_streams, hipMemcpyDeviceToHost, c->s_d2h));
-        else HIPCHK(hipMemcpyAsync(c->hp_pin_out[i], c->hp_dout[i], w_out * c->n_streams, hipMemcpyDeviceToHost, c->s_d2h));
-        HIPCHK(hipEventRecord(c->ev_d2h[i], c->s_d2h));
-        pend_t0[i] = t0; pend_tc[i] = tc;
+        t0 += tc;
     }
     HIPCHK(hipEventRecord(c->ev1, s));
-    const int runs = (n_frames + Tc - 1) / Tc;
-    for (int k = runs > 2 ? runs - 2 : 0; k < runs; k++) {
-        const int i = k & 1;
-        HIPCHK(hipEventSynchronize(c->ev_d2h[i]));
-        if (!pin_out) for (int st = 0; st < c->n_streams; st++)
-            memcpy((uint8_t*)out + st * out_pitch + (size_t)pend_t0[i] * out_stride, c->hp_pin_out[i] + (size_t)st * pend_tc[i] * out_stride, (size_t)pend_tc[i] * out_stride);
-    }
+    HIPCHK(hipMemcpyAsync(out, c->d_out, out_bytes, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
-    /* the status bytes of a host call are those of its last run only when it was cut; callers that want them use one run (n_frames <= 8 or device pointers) */
     float ms = 0; if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->last_ms = ms;
     return 0;
 }
@@ -2912,7 +2899,7 @@ extern "C" int lc3hip_encode(void* ctx, const void* pcm, int pcm_on_device, int 
         dtr = c->d_trace;
     }
     HIPCHK(hipEventRecord(c->ev0, s));
-    if (enc_launch(c, dpcm, bitdepth, n_frames, dout, out_stride, s, dtr)) return 1;
+    if (enc_launch(c, dpcm, bitdepth, n_frames, dout, out_stride, s, dtr, n_frames, 0, true)) return 1;
     HIPCHK(hipEventRecord(c->ev1, s));
     if (!out_on_device) HIPCHK(hipMemcpyAsync(out, dout, out_bytes, hipMemcpyDeviceToHost, s));
     if (trace_host) HIPCHK(hipMemcpyAsync(trace_host, dtr, sizeof(lc3d_trace) * (size_t)c->ncs * n_frames, hipMemcpyDeviceToHost, s));
@@ -2959,15 +2946,11 @@ extern "C" int lc3hip_destroy(void* ctx)
     if (c->d_status) hipFree(c->d_status);
     for (int i = 0; i < 2; i++) {
         if (c->hp_dpcm[i]) hipFree(c->hp_dpcm[i]);
-        if (c->hp_dout[i]) hipFree(c->hp_dout[i]);
         if (c->hp_pin_in[i]) hipHostFree(c->hp_pin_in[i]);
-        if (c->hp_pin_out[i]) hipHostFree(c->hp_pin_out[i]);
         if (c->ev_h2d[i]) hipEventDestroy(c->ev_h2d[i]);
         if (c->ev_k[i]) hipEventDestroy(c->ev_k[i]);
-        if (c->ev_d2h[i]) hipEventDestroy(c->ev_d2h[i]);
     }
     if (c->s_h2d) hipStreamDestroy(c->s_h2d);
-    if (c->s_d2h) hipStreamDestroy(c->s_d2h);
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); }

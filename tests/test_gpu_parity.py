@@ -431,3 +431,38 @@ def test_reference_cli_relinked_against_this_library(tmp_path):
         outs.append((re.findall(r"Switching rate from \d+ to \d+", r.stdout), open(o, "rb").read()))
     assert outs[0][0] == outs[1][0] and len(outs[0][0]) >= 2 and outs[0][0][0] == "Switching rate from 64000 to 32000", outs[0][0]
     assert outs[0][1] == outs[1][1]
+
+
+def _pinned(shape, dtype):
+    """numpy array in page-locked host memory (hipHostMalloc through ctypes: the tests do not depend on torch)."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    ptr = C.c_void_p()
+    assert hip.hipHostMalloc(C.byref(ptr), C.c_size_t(n), C.c_uint(0)) == 0
+    buf = (C.c_char * n).from_address(ptr.value)
+    return np.frombuffer(buf, dtype=dtype).reshape(shape)
+
+
+def test_host_pipeline_matches_device_path():
+    """lc3plus_enc_batch_encode with host pointers cuts a large call into runs of frames (H2D of run k+1 beside the kernels of run k, one
+    bitstream pass and one D2H at the end): same bytes as the oracle, state carried from run to run and from call to call, for pinned
+    and for pageable caller memory; the per-frame status words stay clear."""
+    B, T = 2048, 40                                   # 2048 x 40 x 960 B = 75 MB of PCM: cut into three runs
+    pcm = synth_pcm(B, T, 480, 48000, seed=808)
+    amd = _amd()
+    want = _oracle_batch(pcm, 48000, 10.0, 0, [64000] * B, 80)
+    for pinned in (True, False):
+        alloc = _pinned if pinned else (lambda shape, dtype: np.zeros(shape, dtype))
+        hp = alloc((B, T, 480), np.int16); hp[:] = pcm
+        ho = alloc((B, T, 80), np.uint8); ho[:] = 0
+        b = amd.Batch(B, 48000, 1, 10.0, 0, [64000] * B, device=0)
+        b.encode_host(hp, ho)
+        assert (ho == want).all(), pinned
+        assert not b.last_status(T).any()
+        # two calls on a fresh batch: the second continues the streams where the first stopped
+        b = amd.Batch(B, 48000, 1, 10.0, 0, [64000] * B, device=0)
+        h1 = alloc((B, 24, 480), np.int16); h1[:] = pcm[:, :24]; o1 = alloc((B, 24, 80), np.uint8)
+        h2 = alloc((B, T - 24, 480), np.int16); h2[:] = pcm[:, 24:]; o2 = alloc((B, T - 24, 80), np.uint8)
+        b.encode_host(h1, o1); b.encode_host(h2, o2)
+        assert (o1 == want[:, :24]).all() and (o2 == want[:, 24:]).all(), pinned

@@ -1,30 +1,69 @@
 #!/bin/bash
-# One batched GPU-box session: parity tests, bench, rocprofv3 kernel stats and PMC passes.  Usage: bash tools/gpu_round.sh <tag>
+# One batched GPU-box session for the record: bench lines of every workload, rocprofv3 kernel stats and separate PMC passes of the
+# default bench command (counters and traces never in one run), distilled into profiles/<tag>_*.  Usage: bash tools/gpu_round.sh <tag> [workloads]
 set -e
-TAG=${1:-r01}
-OUT=gpurun_out/$TAG
-mkdir -p $OUT
-timeout -k 10 500 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1
-tail -3 $OUT/pytest.log
-timeout -k 10 300 python bench.py --steps 10 --warmup 2 $BENCH_ARGS > $OUT/bench.json 2> $OUT/bench.err
-cat $OUT/bench.json
+TAG=${1:-r02}
+WL=${2:-"c1 c3 c4 c5 d1 d5"}
 ROOT=$PWD
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT $ROOT/profiles
+for w in $WL; do
+  timeout -k 10 240 python bench.py --workload $w --steps 20 --warmup 3 > $OUT/bench_$w.json 2> $OUT/bench_$w.err
+  cut -c1-300 $OUT/bench_$w.json
+done
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $ROOT/$OUT/stats -o s --output-format csv -- python3 $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $ROOT/$OUT/stats.log 2>&1
-for C in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA" "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS"; do
-  N=$(echo $C | tr ' ' '_' | cut -c1-40)
-  timeout -k 10 200 rocprofv3 --pmc $C -d $ROOT/$OUT/pmc_$N -o p --output-format csv -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $ROOT/$OUT/pmc_$N.log 2>&1
+for w in $WL; do
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats -d $OUT/stats_$w -o s --output-format csv -- python3 $ROOT/bench.py --workload $w --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $OUT/stats_$w.log 2>&1
+  echo "progress: stats $w"
+done
+# PMC passes: the metric's workload and the decoder; counters in their own runs
+for w in c1 d1; do
+  for C in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_SCA" "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64"; do
+    N=$(echo $C | tr ' ' '_' | cut -c1-40)
+    timeout -k 10 200 rocprofv3 --pmc $C -d $OUT/pmc_${w}_$N -o p --output-format csv -- python3 $ROOT/bench.py --workload $w --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $OUT/pmc_${w}_$N.log 2>&1
+    echo "progress: pmc $w $N"
+  done
 done
 cd $ROOT
-python - <<PY
-import csv, glob, collections
-acc = collections.defaultdict(list)
-for f in glob.glob("$OUT/pmc_*/*counter_collection.csv"):
-    for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0]
-        if k.startswith("lc3_enc"): acc[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
-with open("$OUT/pmc_summary.txt", "w") as o:
-    for k in sorted(acc): o.write("%s %s %.0f (mean of %d launches)\n" % (k[0], k[1], sum(acc[k]) / len(acc[k]), len(acc[k])))
-print(open("$OUT/pmc_summary.txt").read())
+python3 - <<PY
+import csv, glob, collections, json, os
+out, tag = "$OUT", "$TAG"
+# ---- kernel stats (avg duration per kernel) ----
+for w in "$WL".split():
+    fs = glob.glob("%s/stats_%s/**/*kernel_stats.csv" % (out, w), recursive=True)
+    if fs:
+        rows = [r for r in csv.DictReader(open(fs[0])) if r["Name"].startswith("lc3_")]
+        with open("profiles/%s_%s_kernel_stats.csv" % (tag, w), "w") as o:
+            o.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
+            for r in rows: o.write("%s,%s,%s,%s,%s,%s,%s\n" % (r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]))
+# ---- PMC ----
+summ = {}
+for w in ("c1", "d1"):
+    acc = collections.defaultdict(list)
+    for f in glob.glob("%s/pmc_%s_*/**/*counter_collection.csv" % (out, w), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0]
+            if k.startswith("lc3_"): acc[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
+    with open("profiles/%s_%s_pmc.txt" % (tag, w), "w") as o:
+        for k in sorted(acc): o.write("%s %s %.0f (mean of %d launches)\n" % (k[0], k[1], sum(acc[k]) / len(acc[k]), len(acc[k])))
+    summ[w] = {k: sum(v) / len(v) for k, v in acc.items()}
+def tot(w, c): return sum(v for (k, cn), v in summ[w].items() if cn == c)
+ents = []
+for w, B, T in (("c1", 4096, 64), ("d1", 4096, 64)):
+    if not summ.get(w): continue
+    fetch, write = tot(w, "FETCH_SIZE"), tot(w, "WRITE_SIZE")        # KB; FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md, HBM section)
+    valu, thr, act = tot(w, "SQ_INSTS_VALU"), tot(w, "SQ_THREAD_CYCLES_VALU"), tot(w, "SQ_ACTIVE_INST_VALU")
+    e = {"workload": w, "streams": B, "frames": T, "fetch_size_kb_raw": fetch, "write_size_kb_raw": write,
+         "traffic_bytes": int(2 * fetch * 1000 + write * 1000), "valu_insts": int(valu),
+         "valu_lane_util": round(thr / (act * 4 * 64), 4) if act else None,
+         "per_kernel": {k: {c: v for (kk, c), v in summ[w].items() if kk == k} for k in sorted({kk for kk, _ in summ[w]})}}
+    ents.append(e)
+if ents:
+    top = ents[0]; top["more"] = ents[1:]
+    top["source"] = "tools/gpu_round.sh %s: separate rocprofv3 --pmc passes of python3 bench.py --workload W --steps 2 --warmup 1; all lc3_* kernels of one call summed, mean over launches; FETCH_SIZE doubled per MI355X_MICROARCH.md; lane utilisation = SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU x 4 x 64)" % tag
+    json.dump(top, open("profiles/%s_counters.json" % tag, "w"), indent=1)
+print(open("profiles/%s_c1_pmc.txt" % tag).read()[:3000])
 PY
-head -3 $OUT/stats/*kernel_stats.csv | cut -c1-200
+for w in $WL; do cp $OUT/bench_$w.json profiles/${TAG}_bench_$w.json; done
+mkdir -p $OUT/profiles && cp profiles/${TAG}_* $OUT/profiles/
+ls profiles
