@@ -43,7 +43,7 @@ for w in ("c1", "d1"):
     for f in glob.glob("%s/pmc_%s_*/**/*counter_collection.csv" % (out, w), recursive=True):
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0]
-            if k.startswith("lc3_"): acc[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
+            if k.startswith("lc3_dec" if w[0] == "d" else "lc3_enc"): acc[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
     with open("profiles/%s_%s_pmc.txt" % (tag, w), "w") as o:
         for k in sorted(acc): o.write("%s %s %.0f (mean of %d launches)\n" % (k[0], k[1], sum(acc[k]) / len(acc[k]), len(acc[k])))
     summ[w] = {k: sum(v) / len(v) for k, v in acc.items()}
@@ -52,15 +52,15 @@ ents = []
 for w, B, T in (("c1", 4096, 64), ("d1", 4096, 64)):
     if not summ.get(w): continue
     fetch, write = tot(w, "FETCH_SIZE"), tot(w, "WRITE_SIZE")        # KB; FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md, HBM section)
-    valu, thr, act = tot(w, "SQ_INSTS_VALU"), tot(w, "SQ_THREAD_CYCLES_VALU"), tot(w, "SQ_ACTIVE_INST_VALU")
+    valu, thr = tot(w, "SQ_INSTS_VALU"), tot(w, "SQ_THREAD_CYCLES_VALU")
     e = {"workload": w, "streams": B, "frames": T, "fetch_size_kb_raw": fetch, "write_size_kb_raw": write,
          "traffic_bytes": int(2 * fetch * 1000 + write * 1000), "valu_insts": int(valu),
-         "valu_lane_util": round(thr / (act * 4 * 64), 4) if act else None,
+         "valu_lane_util": round(thr / (valu * 64), 4) if valu else None,
          "per_kernel": {k: {c: v for (kk, c), v in summ[w].items() if kk == k} for k in sorted({kk for kk, _ in summ[w]})}}
     ents.append(e)
 if ents:
     top = ents[0]; top["more"] = ents[1:]
-    top["source"] = "tools/gpu_round.sh %s: separate rocprofv3 --pmc passes of python3 bench.py --workload W --steps 2 --warmup 1; all lc3_* kernels of one call summed, mean over launches; FETCH_SIZE doubled per MI355X_MICROARCH.md; lane utilisation = SQ_THREAD_CYCLES_VALU / (SQ_ACTIVE_INST_VALU x 4 x 64)" % tag
+    top["source"] = "tools/gpu_round.sh %s: separate rocprofv3 --pmc passes of python3 bench.py --workload W --steps 2 --warmup 1; all lc3_* kernels of one call summed, mean over launches; FETCH_SIZE doubled per MI355X_MICROARCH.md; lane utilisation = SQ_THREAD_CYCLES_VALU / (SQ_INSTS_VALU x 64): the share of lanes the EXEC mask enables per vector instruction (calibration: 64.0 for lc3_enc_hp50_kernel, whose lanes are all live)" % tag
     json.dump(top, open("profiles/%s_counters.json" % tag, "w"), indent=1)
 print(open("profiles/%s_c1_pmc.txt" % tag).read()[:3000])
 PY
