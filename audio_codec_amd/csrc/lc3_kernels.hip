@@ -126,6 +126,8 @@ enum { I_OLPA_PITCH = 0, I_LTPF_ON, I_ATT_POS, I_ATT_FLAG, I_MEM_TARGET, I_MEM_S
 __device__ __forceinline__ float m_log2f(float x) { return (float)log2((double)x); }
 __device__ __forceinline__ float m_log10f(float x) { return (float)log10((double)x); }
 __device__ __forceinline__ float m_powf(float x, float y) { return (float)pow((double)x, (double)y); }
+/* powf(2, y): the same value from the much shorter exp2 (both are far inside half an ulp of a double before the rounding to float) */
+__device__ __forceinline__ float m_pow2f(float y) { return (float)exp2((double)y); }
 __device__ __forceinline__ float mul_d(float a, double c) { return (float)((double)a * c); }
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
@@ -1450,7 +1452,7 @@ STAGE void st_sns_apply(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
         }
         LSYNC();
     }
-    if (lane < nb) gi[lane] = m_powf(2.0f, -v);
+    if (lane < nb) gi[lane] = m_pow2f(-v);
     LSYNC();
     for (int j = lane; j < PI(N); j += WAVE) {
         const int b = P->band_of_bin[j];
@@ -2520,6 +2522,14 @@ KERNEL_NAME(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans
     long long tlast = clock64();
 #endif
 
+    /* The next frame's PCM (16 bytes per lane when the layout allows) and 12.8 kHz samples are requested one frame ahead and wait
+     * in registers: a wave has nothing else to hide a global-memory round trip with at the top of a frame. */
+    const bool fast16 = bitdepth == 16 && (N & 7) == 0 && N <= 8 * WAVE && ((((size_t)pcm) + (((size_t)strm * T) * channels + ch) * N * 2) & 15) == 0 && ((N * 2 * channels) & 15) == 0;
+    uint4 nv = make_uint4(0, 0, 0, 0); float ny0 = 0, ny1 = 0;
+    if (T > 0) {
+        if (fast16 && lane < (N >> 3)) nv = ((const uint4*)((const int16_t*)pcm + (((size_t)strm * T) * channels + ch) * N))[lane];
+        if (y12) { const float* yp = y12 + ((size_t)cs * T) * 128; ny0 = lane < PI(len12) ? yp[lane] : 0.0f; ny1 = lane + 64 < PI(len12) ? yp[lane + 64] : 0.0f; }
+    }
     for (int t = 0; t < T; t++) {
 #ifdef LC3_STAGE_TIMING
         lc3d_trace* tr = nullptr;
@@ -2528,18 +2538,19 @@ KERNEL_NAME(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans
 #endif
         /* ---- PCM in (R/enc_lc3_fl.c:30-42) ---- */
         const size_t fidx = ((size_t)strm * T + t) * channels + ch;
-        if (bitdepth == 16) {
+        if (fast16) {
+            if (lane < (N >> 3)) {
+                const uint4 v = nv;
+                float* d = &XCUR(L)[8 * lane];
+                d[0] = (float)(int16_t)(v.x & 0xffff); d[1] = (float)(int16_t)(v.x >> 16);
+                d[2] = (float)(int16_t)(v.y & 0xffff); d[3] = (float)(int16_t)(v.y >> 16);
+                d[4] = (float)(int16_t)(v.z & 0xffff); d[5] = (float)(int16_t)(v.z >> 16);
+                d[6] = (float)(int16_t)(v.w & 0xffff); d[7] = (float)(int16_t)(v.w >> 16);
+            }
+            if (t + 1 < T && lane < (N >> 3)) nv = ((const uint4*)((const int16_t*)pcm + (fidx + channels) * N))[lane];
+        } else if (bitdepth == 16) {
             const int16_t* p = (const int16_t*)pcm + fidx * N;
-            if ((N & 7) == 0 && (((size_t)p) & 15) == 0) {          /* 16 B per lane: one wave-wide load for N <= 512 */
-                for (int i = lane; i < (N >> 3); i += WAVE) {
-                    const uint4 v = ((const uint4*)p)[i];
-                    float* d = &XCUR(L)[8 * i];
-                    d[0] = (float)(int16_t)(v.x & 0xffff); d[1] = (float)(int16_t)(v.x >> 16);
-                    d[2] = (float)(int16_t)(v.y & 0xffff); d[3] = (float)(int16_t)(v.y >> 16);
-                    d[4] = (float)(int16_t)(v.z & 0xffff); d[5] = (float)(int16_t)(v.z >> 16);
-                    d[6] = (float)(int16_t)(v.w & 0xffff); d[7] = (float)(int16_t)(v.w >> 16);
-                }
-            } else for (int i = lane; i < N; i += WAVE) XCUR(L)[i] = (float)p[i];
+            for (int i = lane; i < N; i += WAVE) XCUR(L)[i] = (float)p[i];
         } else {
             const int32_t* p = (const int32_t*)pcm + fidx * N;
             const float sc = bitdepth == 24 ? 256.0f : 65536.0f;
@@ -2548,7 +2559,20 @@ KERNEL_NAME(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans
         LSYNC();
         TICK(0);
 
-        st_resample(P, L, lane, y12 ? y12 + ((size_t)cs * T + t) * 128 : nullptr);
+        if (y12) {                                       /* lc3_enc_resample_kernel + lc3_enc_hp50_kernel (lc3_enc_pre.inc) have done the work */
+            const int len12 = PI(len12);
+            const float y0 = ny0, y1 = ny1;
+            if (t + 1 < T) { const float* yp = y12 + ((size_t)cs * T + t + 1) * 128; ny0 = lane < len12 ? yp[lane] : 0.0f; ny1 = lane + 64 < len12 ? yp[lane + 64] : 0.0f; }
+            float keep[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) { const int i = lane + 64 * k; keep[k] = (i + len12 < 384) ? L.h12[i + len12] : 0.0f; }
+            LSYNC();
+#pragma unroll
+            for (int k = 0; k < 6; k++) { const int i = lane + 64 * k; if (i + len12 < 384) L.h12[i] = keep[k]; }
+            if (lane < len12) L.h12[384 - len12 + lane] = y0;
+            if (lane + 64 < len12) L.h12[384 - len12 + 64 + lane] = y1;
+            LSYNC();
+        } else st_resample(P, L, lane, nullptr);
         TICK(2);
         if (tr) for (int i = lane; i < PI(len12) + 1; i += WAVE) tr->s12k8[i] = L.h12[384 - PI(len12) - 24 + i];
         st_olpa(P, L, lane);
