@@ -2725,6 +2725,7 @@ struct lc3hip_ctx {
     hipStream_t stream, last_stream; hipEvent_t ev0, ev1; float last_ms;
 };
 
+#define LC3D_FUSED_MAX_T 4
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "lc3plus_hip: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); return 1; } } while (0)
 /* inside the create functions: release what has been allocated so far (the caller only sees ctx == NULL) */
 #define HIPCHK_OR(x, cleanup) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "lc3plus_hip: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); cleanup; return 1; } } while (0)
@@ -2789,8 +2790,12 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
     /* two kernels: lc3_encode_kernel (one wave per channel-stream, frames in order) leaves each frame's parameters and quantised
      * spectrum in a record; lc3_enc_pack_kernel (one channel-frame per lane, any frame size) writes the bytes.  With stage traces,
      * or with LC3PLUS_ENC_FUSED=1 (diagnostic), the first kernel writes the bytes itself. */
+    /* A call of very few frames is latency bound and the one-frame-per-lane writer is the longest chain in it (~0.19 ms for a frame of
+     * 80 bytes whatever the batch size): up to LC3D_FUSED_MAX_T frames per call the wave-parallel writer inside the first kernel
+     * (st_bitstream, ~6 us per frame) is used instead - the single-stream lc3_enc_* API and T = 1 batches live here. */
     int* ddump = nullptr; int dstride = 0;
-    if (!dtr && !c->fused) {
+    const bool in_kernel_writer = dtr || c->fused || dT <= LC3D_FUSED_MAX_T;
+    if (!in_kernel_writer) {
         dstride = PK_STRIDE(c->N, c->hr);
         const size_t need = (size_t)c->ncs * dT * dstride;
         if (c->dump_cap < need) { if (c->d_dump) HIPCHK(hipFree(c->d_dump)); c->d_dump = nullptr; c->dump_cap = 0; HIPCHK(hipMalloc((void**)&c->d_dump, need * sizeof(int))); c->dump_cap = need; }
@@ -2855,7 +2860,7 @@ static int encode_host(lc3hip_ctx* c, const void* pcm, int bitdepth, int n_frame
     const size_t pcm_bytes = (size_t)c->n_streams * n_frames * fr_in, out_bytes = (size_t)c->n_streams * n_frames * out_stride;
     int K = (int)(pcm_bytes >> 25);                                           /* ~32 MB of PCM per run */
     if (K < 1) K = 1; if (K > 8) K = 8; if (K > n_frames) K = n_frames;
-    if (c->fused) K = 1;                                                      /* diagnostic single-kernel path: the first kernel addresses the output by its own frame count */
+    if (c->fused || n_frames <= LC3D_FUSED_MAX_T) K = 1;                                                      /* diagnostic single-kernel path: the first kernel addresses the output by its own frame count */
     const int Tc = (n_frames + K - 1) / K, T0 = K > 1 ? (Tc + 1) / 2 : Tc;   /* first run: half a run */
     const bool pin_in = host_ptr_is_pinned(pcm);
     const size_t cin = (size_t)c->n_streams * Tc * fr_in;
