@@ -1418,7 +1418,7 @@ STAGE void st_sns_vq(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
 }
 
 /* ---- SNS interpolation R/sns_interpolate_scf.c:13-89 and spectral shaping R/mdct_shaping.c:13-22 ---- */
-STAGE void st_sns_apply(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
+STAGE void st_sns_apply(const lc3d_plan* __restrict__ P, WaveLds& L, int lane, const float* src /* the MDCT spectrum: L.A, or where the front kernel's copy was parked */)
 {
     const float* g = &L.sm[SM_SCFQ];
     float* gi = &L.sm[SM_GI];
@@ -1456,7 +1456,8 @@ STAGE void st_sns_apply(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
     LSYNC();
     for (int j = lane; j < PI(N); j += WAVE) {
         const int b = P->band_of_bin[j];
-        if (b < nb) L.A[j] = L.A[j] * gi[b];
+        const float x = src[j];
+        L.A[j] = b < nb ? x * gi[b] : x;
     }
     LSYNC();
 }
@@ -2493,7 +2494,10 @@ KERNEL_NAME(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans
                   lc3d_trace* __restrict__ trace, int* __restrict__ dump /* [cs][T][dstride] hand-over to lc3_enc_pack_kernel, or null: write the bytes here */, int dstride,
                   const float* __restrict__ y12 /* [cs][T][128] HP-filtered 12.8 kHz signal from the pre-kernels, or null: resample here */,
                   uint8_t* __restrict__ status /* [cs][dT] LC3D_ENC_ST_* bits (zeroed by the host), or null */,
-                  int dT, int dt0 /* the hand-over and the status rows hold dT frames per channel-stream; this launch's frame t is their frame dt0 + t */)
+                  int dT, int dt0 /* the hand-over and the status rows hold dT frames per channel-stream; this launch's frame t is their frame dt0 + t */,
+                  const float* __restrict__ spec /* [cs][T][N] MDCT spectra from lc3_enc_front_kernel, or null: transform here */,
+                  const float* __restrict__ frec /* [cs][T][FR_WORDS] with the SNS result of lc3_enc_snsvq_kernel */,
+                  const float* __restrict__ xnext /* [cs][MEMCAP] MDCT memory after the last frame */)
 {
     __shared__ WaveLds L;
     const int lane = threadIdx.x;
@@ -2526,6 +2530,15 @@ KERNEL_NAME(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans
      * in registers: a wave has nothing else to hide a global-memory round trip with at the top of a frame. */
     const bool fast16 = bitdepth == 16 && (N & 7) == 0 && N <= 8 * WAVE && ((((size_t)pcm) + (((size_t)strm * T) * channels + ch) * N * 2) & 15) == 0 && ((N * 2 * channels) & 15) == 0;
     uint4 nv = make_uint4(0, 0, 0, 0); float ny0 = 0, ny1 = 0;
+    constexpr int SPK = (MAXN + WAVE - 1) / WAVE;
+    float sp[SPK]; float rq = 0; int ri = 0;
+#pragma unroll
+    for (int k = 0; k < SPK; k++) sp[k] = 0;
+#define SPEC_PREFETCH(t_) do { const float* sr_ = spec + ((size_t)cs * T + (t_)) * N; const float* fr_ = frec + ((size_t)cs * T + (t_)) * FR_WORDS; \
+        _Pragma("unroll") for (int k = 0; k < SPK; k++) sp[k] = lane + 64 * k < N ? sr_[lane + 64 * k] : 0.0f; \
+        if (lane < 16) rq = fr_[FR_SCFQ + lane]; \
+        if (lane < 8) ri = ((const int*)fr_)[FR_IDX + lane];   /* seven indices, then the bandwidth index */ } while (0)
+    if (spec && T > 0) SPEC_PREFETCH(0);
     if (T > 0) {
         if (fast16 && lane < (N >> 3)) nv = ((const uint4*)((const int16_t*)pcm + (((size_t)strm * T) * channels + ch) * N))[lane];
         if (y12) { const float* yp = y12 + ((size_t)cs * T) * 128; ny0 = lane < PI(len12) ? yp[lane] : 0.0f; ny1 = lane + 64 < PI(len12) ? yp[lane + 64] : 0.0f; }
@@ -2538,7 +2551,15 @@ KERNEL_NAME(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans
 #endif
         /* ---- PCM in (R/enc_lc3_fl.c:30-42) ---- */
         const size_t fidx = ((size_t)strm * T + t) * channels + ch;
-        if (fast16) {
+        /* the frame's spectrum and SNS record from the frame-parallel front were requested at the end of the previous frame: park them in
+         * LDS (the frame half of xbuf is free until the quantiser needs it) */
+        if (spec) {
+#pragma unroll
+            for (int k = 0; k < SPK; k++) if (lane + 64 * k < N) XCUR(L)[lane + 64 * k] = sp[k];
+            if (lane < 16) L.sm[SM_SCFQ + lane] = rq;
+            if (lane < 7) L.isc[I_SCF0 + lane] = ri;
+            if (lane == 7) L.isc[I_BW] = ri;
+        } else if (fast16) {
             if (lane < (N >> 3)) {
                 const uint4 v = nv;
                 float* d = &XCUR(L)[8 * lane];
@@ -2579,6 +2600,9 @@ KERNEL_NAME(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans
         TICK(3);
         st_ltpf(P, C, L, lane);
         TICK(4);
+        if (spec) {
+            TICK(5); TICK(1); TICK(6); TICK(7); TICK(8);
+        } else {
         if (CI(attack_handling)) st_attack(P, L, lane);
         TICK(5);
         mdct_pre(P, L, lane);
@@ -2602,7 +2626,8 @@ KERNEL_NAME(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans
         if (tr && lane < 16) tr->scf[lane] = L.sm[SM_SCF + lane];
         st_sns_vq(P, L, lane);
         TICK(8);
-        st_sns_apply(P, L, lane);
+        }
+        st_sns_apply(P, L, lane, spec ? XCUR(L) : L.A);
         TICK(9);
         if (tr) { if (lane < 16) tr->scf_q[lane] = L.sm[SM_SCFQ + lane]; if (lane < 7) tr->scf_idx[lane] = L.isc[I_SCF0 + lane];
                   for (int i = lane; i < N; i += WAVE) tr->spec_shaped[i] = L.A[i]; }
@@ -2651,6 +2676,7 @@ KERNEL_NAME(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans
         if (uni(L.isc[I_LSB]) == 0) st_residual(P, L, lane, tbq, uni(L.isc[I_NBITS2]));
         else { for (int i = lane; i < 160; i += WAVE) ((uint32_t*)RESB(L))[i] = 0; if (lane == 0) L.isc[I_NRES] = 0; LSYNC(); }
         TICK(15);
+        if (spec && t + 1 < T) SPEC_PREFETCH(t + 1);
         if (dump) {
             /* the bitstream of a frame depends on nothing but this: scalars, residual bits, quantised lines up to lastnz.  The
              * serial writer runs one frame per lane in lc3_enc_pack_kernel. */
@@ -2692,7 +2718,7 @@ KERNEL_NAME(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans
     if (trace && lane < NSTAGE) ((long long*)&trace[(size_t)cs * T])[lane] = L.tacc[lane];
 #endif
     /* ---- store cross-frame state ---- */
-    for (int i = lane; i < MEMCAP; i += WAVE) stp[LC3D_ST_XPREV + i] = L.xbuf[i];
+    for (int i = lane; i < MEMCAP; i += WAVE) stp[LC3D_ST_XPREV + i] = spec ? xnext[(size_t)cs * MEMCAP + i] : L.xbuf[i];
     for (int i = lane; i < 384; i += WAVE) stp[LC3D_ST_H12(MEMCAP) + i] = L.h12[i];
     for (int i = lane; i < 194; i += WAVE) stp[LC3D_ST_H6(MEMCAP) + i] = L.h6[i];
     if (lane < 12 && !(y12 && lane < 2)) stp[LC3D_ST_SCAL(MEMCAP) + lane] = L.fsc[lane];      /* the HP50 state belongs to lc3_enc_hp50_kernel when it runs */
@@ -2703,14 +2729,19 @@ KERNEL_NAME(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans
 /* ------------------------------------------------------------------------------------------------ */
 /* C-ABI device shim (lc3_shim.h): context, uploads, launch                                          */
 /* ------------------------------------------------------------------------------------------------ */
+#include "lc3_enc_front.inc"       /* lc3_enc_front_kernel (or _big): the stateless front, frame-parallel */
 #include "lc3_dec_kernels.inc"     /* lc3_dec_{plc,imdct,synth}_kernel, or the _big imdct / synth kernels in the large-layout object */
 #ifndef LC3_BIG                 /* the large-layout object holds only its kernels */
 #include "lc3_dec_parse.inc"
 extern "C" __global__ void lc3_encode_kernel_big(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans, float* __restrict__ state,
                                                  const void* __restrict__ pcm, int bitdepth, int T, uint8_t* __restrict__ out, int out_stride, int ncs,
                                                  lc3d_trace* __restrict__ trace, int* __restrict__ dump, int dstride, const float* __restrict__ y12,
-                                                 uint8_t* __restrict__ status, int dT, int dt0);
+                                                 uint8_t* __restrict__ status, int dT, int dt0, const float* __restrict__ spec, const float* __restrict__ frec,
+                                                 const float* __restrict__ xnext);
+extern "C" __global__ void lc3_enc_front_kernel_big(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans, const float* __restrict__ state, const void* __restrict__ pcm,
+                                                    int bitdepth, int T, int ncs, float* __restrict__ spec, float* __restrict__ rec, float* __restrict__ xnext);
 #include "lc3_enc_pack.inc"
+#include "lc3_enc_snsvq.inc"
 #include "lc3_enc_pre.inc"
 struct lc3hip_ctx {
     int device, ncs, n_streams, channels, N, big, state_words;
@@ -2718,7 +2749,8 @@ struct lc3hip_ctx {
     void* d_pcm; size_t pcm_cap; uint8_t* d_out; size_t out_cap;
     lc3d_trace* d_trace; size_t trace_cap;
     int* d_dump; size_t dump_cap; int hr, fused; float* d_y12; size_t y12_cap;
-    uint8_t* d_status; size_t status_cap; int status_frames;      /* per channel-frame status bits of the last call (LC3D_ENC_ST_*) */
+    uint8_t* d_status; size_t status_cap; int status_frames;
+    float* d_spec; size_t spec_cap; float* d_frec; size_t frec_cap; float* d_xnext; uint8_t* h_attack; int any_attack;   /* split path (lc3_enc_front.inc) */      /* per channel-frame status bits of the last call (LC3D_ENC_ST_*) */
     /* host-pointer pipeline (lc3hip_encode_host): two chunk slots, each with device staging and (for pageable callers) pinned staging */
     void* hp_dpcm[2]; void* hp_pin_in[2]; size_t hp_pcm_cap, hp_pin_in_cap;
     hipStream_t s_h2d; hipEvent_t ev_h2d[2], ev_k[2];
@@ -2778,6 +2810,11 @@ extern "C" int lc3hip_upload_chans(void* ctx, const lc3d_chan* chans, int first,
      * wait for: drain the stream the last launch went to first */
     if (c->last_stream) { HIPCHK(hipStreamSynchronize(c->last_stream)); c->last_stream = nullptr; }
     HIPCHK(hipMemcpy(c->d_chans + first, chans, sizeof(lc3d_chan) * count, hipMemcpyHostToDevice));
+    /* the frame-parallel front cannot serve streams with attack handling (the detector is sequential and feeds the scale factors) */
+    if (!c->h_attack) { c->h_attack = (uint8_t*)calloc((size_t)c->ncs, 1); if (!c->h_attack) return 1; }
+    for (int i = 0; i < count; i++) c->h_attack[first + i] = chans[i].attack_handling != 0;
+    c->any_attack = 0;
+    for (int i = 0; i < c->ncs; i++) c->any_attack |= c->h_attack[i];
     return 0;
 }
 
@@ -2821,10 +2858,29 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
         hipLaunchKernelGGL(lc3_enc_hp50_kernel, dim3((unsigned)((c->ncs + WAVE - 1) / WAVE)), dim3(WAVE), 0, s, c->d_plan, c->d_state, c->state_words, LC3D_ST_SCAL(mc), n_frames, c->ncs, dy12);
         HIPCHK(hipGetLastError());
     }
+    /* the stateless front (MDCT ... scale factors) for all frames at once, the SNS quantiser one frame per lane, then the sequential
+     * kernel; batches with attack handling, traced and diagnostic launches keep everything in the sequential kernel */
+    float* dspec = nullptr; float* dfrec = nullptr;
+    { static int split_off = -1; if (split_off < 0) { const char* e = getenv("LC3PLUS_ENC_NO_SPLIT"); split_off = e && e[0] == '1'; }
+      if (dy12 && !c->any_attack && !split_off) {
+        const int mc = c->big ? LC3D_MEMCAP_BIG : LC3D_MEMCAP_STD;
+        const size_t ns = (size_t)c->ncs * n_frames * c->N, nr = (size_t)c->ncs * n_frames * FR_WORDS;
+        if (c->spec_cap < ns) { if (c->d_spec) HIPCHK(hipFree(c->d_spec)); c->d_spec = nullptr; c->spec_cap = 0; HIPCHK(hipMalloc((void**)&c->d_spec, ns * sizeof(float))); c->spec_cap = ns; }
+        if (c->frec_cap < nr) { if (c->d_frec) HIPCHK(hipFree(c->d_frec)); c->d_frec = nullptr; c->frec_cap = 0; HIPCHK(hipMalloc((void**)&c->d_frec, nr * sizeof(float))); c->frec_cap = nr; }
+        if (!c->d_xnext) HIPCHK(hipMalloc((void**)&c->d_xnext, (size_t)c->ncs * mc * sizeof(float)));
+        dspec = c->d_spec; dfrec = c->d_frec;
+        const unsigned runs = (unsigned)((n_frames + FRONT_FPW - 1) / FRONT_FPW);
+        if (c->big) hipLaunchKernelGGL(lc3_enc_front_kernel_big, dim3((unsigned)c->ncs * runs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames, c->ncs, dspec, dfrec, c->d_xnext);
+        else hipLaunchKernelGGL(lc3_enc_front_kernel, dim3((unsigned)c->ncs * runs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames, c->ncs, dspec, dfrec, c->d_xnext);
+        HIPCHK(hipGetLastError());
+        const long long nfr = (long long)c->ncs * n_frames;
+        hipLaunchKernelGGL(lc3_enc_snsvq_kernel, dim3((unsigned)((nfr + WAVE - 1) / WAVE)), dim3(WAVE), 0, s, c->d_plan, dfrec, nfr);
+        HIPCHK(hipGetLastError());
+      } }
     if (c->big) hipLaunchKernelGGL(lc3_encode_kernel_big, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames,
-                                   dout, out_stride, c->ncs, dtr, ddump, dstride, dy12, c->d_status, dT, dt0);
+                                   dout, out_stride, c->ncs, dtr, ddump, dstride, dy12, c->d_status, dT, dt0, dspec, dfrec, c->d_xnext);
     else hipLaunchKernelGGL(lc3_encode_kernel, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames,
-                            dout, out_stride, c->ncs, dtr, ddump, dstride, dy12, c->d_status, dT, dt0);
+                            dout, out_stride, c->ncs, dtr, ddump, dstride, dy12, c->d_status, dT, dt0, dspec, dfrec, c->d_xnext);
     if (ddump && pack) {
         HIPCHK(hipGetLastError());
         const int wpg = 4;
@@ -2973,6 +3029,10 @@ extern "C" int lc3hip_destroy(void* ctx)
     if (c->d_y12) hipFree(c->d_y12);
     if (c->d_trace) hipFree(c->d_trace);
     if (c->d_status) hipFree(c->d_status);
+    if (c->d_spec) hipFree(c->d_spec);
+    if (c->d_frec) hipFree(c->d_frec);
+    if (c->d_xnext) hipFree(c->d_xnext);
+    free(c->h_attack);
     for (int i = 0; i < 2; i++) {
         if (c->hp_dpcm[i]) hipFree(c->hp_dpcm[i]);
         if (c->hp_pin_in[i]) hipHostFree(c->hp_pin_in[i]);

@@ -68,6 +68,15 @@ typedef struct {
 #define LC3D_STATE_WORDS(mc) ((mc) + 660)
 #define LC3D_STATE_WORDS_MAX LC3D_STATE_WORDS(LC3D_MEMCAP_BIG)
 
+/* hand-over from the frame-parallel front of the encoder (lc3_enc_front_kernel: MDCT, band energies, bandwidth, SNS scale factors) through
+ * the one-frame-per-lane vector quantiser (lc3_enc_snsvq_kernel) to the sequential kernel: per channel-frame a record of FR_WORDS words
+ * and the MDCT spectrum row of N floats */
+#define FR_SCF   0                       /* 16 floats: scale factors (R/sns_compute_scf.c) */
+#define FR_SCFQ  16                      /* 16 floats: quantised scale factors (R/sns_quantize_scf.c) */
+#define FR_IDX   32                      /* 7 ints: the SNS indices */
+#define FR_BW    39                      /* int: bandwidth index (R/detect_cutoff_warped.c) */
+#define FR_WORDS 48
+
 /* per channel-frame status bits of the encoder: conditions the reference only asserts on (SURVEY 5 "failure detection") */
 #define LC3D_ENC_ST_BIT_BUDGET  1        /* side information + range-coder bits exceed the frame (R/ari_codec.c:777) */
 #define LC3D_ENC_ST_QUANT_RANGE 2        /* a quantised line outside int16 without the high-resolution mode (R/quantize_spec.c:50) */
