@@ -669,12 +669,13 @@ STAGE void st_ltpf(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict_
 }
 
 /* ---- attack detector: R/attack_detector.c:13-104 (only when attack_handling) ---- */
-STAGE void st_attack(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
+/* first half (:26-77): decimation to 16 kHz, high-pass with the filter memory (m0, m1) of the previous frame, block energies: lane b < nb
+ * returns block b's energy; (nm0, nm1) is the filter memory this frame leaves.  Stateless given the previous frame's last samples. */
+__device__ __forceinline__ float attack_energies(WaveLds& L, int lane, float m0, float m1, float& nm0, float& nm1)
 {
     const int nb = PI(att_nblocks), n16 = nb * 40;
     const float* in = XCUR(L);
     float* p = &L.A[2];
-    float mval = 0;
     for (int j = lane; j < n16; j += WAVE) {
         float v;
         if (PI(fs) == 96000) { const float* q = &in[6 * j]; v = q[0] + q[1] + q[2] + q[3] + q[4] + q[5]; }
@@ -683,10 +684,9 @@ STAGE void st_attack(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
         else { const float* q = &in[3 * j]; v = (float)((double)q[0] + ((double)(q[1] + q[2])) / 2.0); }
         p[j] = v;
     }
-    if (PI(fs) == 96000) mval = 1e-5f;
-    if (lane == 0) { p[-2] = L.fsc[F_ATT_M0]; p[-1] = L.fsc[F_ATT_M1]; }
+    if (lane == 0) { p[-2] = m0; p[-1] = m1; }
     LSYNC();
-    const float nm0 = p[n16 - 2], nm1 = p[n16 - 1];
+    nm0 = p[n16 - 2]; nm1 = p[n16 - 1];
     float* fs = &L.A[200];
     for (int i = lane; i < 160; i += WAVE) {
         float t = 0;
@@ -698,16 +698,32 @@ STAGE void st_attack(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
     LSYNC();
     float e = 0;
     if (lane < nb) { for (int k = 0; k < 40; k++) { const float v = fs[k + lane * 40]; e += v * v; } }
-    int flag = 0, pos = -1;
-    float acc = unif(L.fsc[F_ATT_ACC]);
-    for (int b = 0; b < nb; b++) {
-        const float nrg = rl_f(e, b);
-        const float t = (float)((double)nrg / 8.5);
-        if (t > (acc > mval ? acc : mval)) { flag = 1; pos = b + 1; }
-        const double q = 0.25 * (double)acc;
-        acc = (double)nrg > q ? nrg : (float)q;
+    return e;
+}
+/* second half (:79-102): the decision over the blocks, sequential from frame to frame through (acc, last position) */
+__device__ __forceinline__ void attack_decide(float e0, float e1, float e2, float e3, int nb, float mval, int hang, float& acc, int& last_pos, int& flag)
+{
+    const float ev[4] = {e0, e1, e2, e3};
+    flag = 0; int pos = -1;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        if (b < nb) {
+            const float nrg = ev[b];
+            const float t = (float)((double)nrg / 8.5);
+            if (t > (acc > mval ? acc : mval)) { flag = 1; pos = b + 1; }
+            const double q = 0.25 * (double)acc;
+            acc = (double)nrg > q ? nrg : (float)q;
+        }
     }
-    if (uni(L.isc[I_ATT_POS]) > PI(att_hang)) flag = 1;
+    if (last_pos > hang) flag = 1;
+    last_pos = pos;
+}
+STAGE void st_attack(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
+{
+    float nm0, nm1;
+    const float e = attack_energies(L, lane, unif(L.fsc[F_ATT_M0]), unif(L.fsc[F_ATT_M1]), nm0, nm1);
+    float acc = unif(L.fsc[F_ATT_ACC]); int pos = uni(L.isc[I_ATT_POS]), flag;
+    attack_decide(rl_f(e, 0), rl_f(e, 1), rl_f(e, 2), rl_f(e, 3), PI(att_nblocks), PI(fs) == 96000 ? 1e-5f : 0.0f, PI(att_hang), acc, pos, flag);
     LSYNC();
     if (lane == 0) { L.fsc[F_ATT_M0] = nm0; L.fsc[F_ATT_M1] = nm1; L.fsc[F_ATT_ACC] = acc; L.isc[I_ATT_FLAG] = flag; L.isc[I_ATT_POS] = pos; }
     LSYNC();
@@ -2721,8 +2737,9 @@ KERNEL_NAME(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans
     for (int i = lane; i < MEMCAP; i += WAVE) stp[LC3D_ST_XPREV + i] = spec ? xnext[(size_t)cs * MEMCAP + i] : L.xbuf[i];
     for (int i = lane; i < 384; i += WAVE) stp[LC3D_ST_H12(MEMCAP) + i] = L.h12[i];
     for (int i = lane; i < 194; i += WAVE) stp[LC3D_ST_H6(MEMCAP) + i] = L.h6[i];
-    if (lane < 12 && !(y12 && lane < 2)) stp[LC3D_ST_SCAL(MEMCAP) + lane] = L.fsc[lane];      /* the HP50 state belongs to lc3_enc_hp50_kernel when it runs */
-    if (lane < 16) ((int*)stp)[LC3D_ST_SCAL(MEMCAP) + 16 + lane] = L.isc[lane];
+    /* the HP50 state belongs to lc3_enc_hp50_kernel when it runs, the attack detector's to lc3_enc_attack_kernel on the split path */
+    if (lane < 12 && !(y12 && lane < 2) && !(spec && lane >= F_ATT_M0 && lane <= F_ATT_ACC)) stp[LC3D_ST_SCAL(MEMCAP) + lane] = L.fsc[lane];
+    if (lane < 16 && !(spec && (lane == I_ATT_POS || lane == I_ATT_FLAG))) ((int*)stp)[LC3D_ST_SCAL(MEMCAP) + 16 + lane] = L.isc[lane];
     (void)ml;
 }
 
@@ -2754,6 +2771,7 @@ struct lc3hip_ctx {
     /* host-pointer pipeline (lc3hip_encode_host): two chunk slots, each with device staging and (for pageable callers) pinned staging */
     void* hp_dpcm[2]; void* hp_pin_in[2]; size_t hp_pcm_cap, hp_pin_in_cap;
     hipStream_t s_h2d; hipEvent_t ev_h2d[2], ev_k[2];
+    hipStream_t s_pre; hipEvent_t ev_fork, ev_join;
     hipStream_t stream, last_stream; hipEvent_t ev0, ev1; float last_ms;
 };
 
@@ -2810,9 +2828,9 @@ extern "C" int lc3hip_upload_chans(void* ctx, const lc3d_chan* chans, int first,
      * wait for: drain the stream the last launch went to first */
     if (c->last_stream) { HIPCHK(hipStreamSynchronize(c->last_stream)); c->last_stream = nullptr; }
     HIPCHK(hipMemcpy(c->d_chans + first, chans, sizeof(lc3d_chan) * count, hipMemcpyHostToDevice));
-    /* the frame-parallel front cannot serve streams with attack handling (the detector is sequential and feeds the scale factors) */
+    /* streams with attack handling need lc3_enc_attack_kernel between the front and the quantiser */
     if (!c->h_attack) { c->h_attack = (uint8_t*)calloc((size_t)c->ncs, 1); if (!c->h_attack) return 1; }
-    for (int i = 0; i < count; i++) c->h_attack[first + i] = chans[i].attack_handling != 0;
+    for (int i = 0; i < count; i++) c->h_attack[first + i] = chans[i].attack_handling != 0 || chans[i].reset_attack != 0;   /* a pending reset needs the kernel too */
     c->any_attack = 0;
     for (int i = 0; i < c->ncs; i++) c->any_attack |= c->h_attack[i];
     return 0;
@@ -2851,18 +2869,30 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
         HIPCHK(hipMemsetAsync(c->d_status, 0, need, s));
         c->status_frames = dT;
     }
+    static int split_off = -1;
+    if (split_off < 0) { const char* e = getenv("LC3PLUS_ENC_NO_SPLIT"); split_off = e && e[0] == '1'; }
+    const bool split = dy12 && !split_off && dT > LC3D_FUSED_MAX_T;
+    hipStream_t sp = s;                    /* where the 12.8 kHz pre-kernels go */
     if (dy12) {
+        if (split) {
+            /* the pitch path's pre-kernels (resampler, HP50: only B / 64 waves, one long chain each) and the spectral front are independent
+             * until the sequential kernel needs both: a second stream lets the HP50 waves run beside the front kernel */
+            if (!c->s_pre) { HIPCHK(hipStreamCreateWithFlags(&c->s_pre, hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)); }
+            HIPCHK(hipEventRecord(c->ev_fork, s)); HIPCHK(hipStreamWaitEvent(c->s_pre, c->ev_fork, 0));
+            sp = c->s_pre;
+        }
         const int mc = c->big ? LC3D_MEMCAP_BIG : LC3D_MEMCAP_STD;
         const unsigned runs = (unsigned)((n_frames + PRE_FPW - 1) / PRE_FPW);
-        hipLaunchKernelGGL(lc3_enc_resample_kernel, dim3((unsigned)c->ncs * runs), dim3(WAVE), 0, s, c->d_plan, c->d_state, c->state_words, mc, dpcm, bitdepth, n_frames, c->ncs, dy12);
-        hipLaunchKernelGGL(lc3_enc_hp50_kernel, dim3((unsigned)((c->ncs + WAVE - 1) / WAVE)), dim3(WAVE), 0, s, c->d_plan, c->d_state, c->state_words, LC3D_ST_SCAL(mc), n_frames, c->ncs, dy12);
+        hipLaunchKernelGGL(lc3_enc_resample_kernel, dim3((unsigned)c->ncs * runs), dim3(WAVE), 0, sp, c->d_plan, c->d_state, c->state_words, mc, dpcm, bitdepth, n_frames, c->ncs, dy12);
+        hipLaunchKernelGGL(lc3_enc_hp50_kernel, dim3((unsigned)((c->ncs + WAVE - 1) / WAVE)), dim3(WAVE), 0, sp, c->d_plan, c->d_state, c->state_words, LC3D_ST_SCAL(mc), n_frames, c->ncs, dy12);
         HIPCHK(hipGetLastError());
+        if (split) HIPCHK(hipEventRecord(c->ev_join, sp));
     }
-    /* the stateless front (MDCT ... scale factors) for all frames at once, the SNS quantiser one frame per lane, then the sequential
-     * kernel; batches with attack handling, traced and diagnostic launches keep everything in the sequential kernel */
+    /* the stateless front (MDCT ... scale factors) for all frames at once, the attack detector's decision one stream per lane, the SNS
+     * quantiser one frame per lane, then the sequential kernel; traced, diagnostic and very short launches keep everything in the
+     * sequential kernel */
     float* dspec = nullptr; float* dfrec = nullptr;
-    { static int split_off = -1; if (split_off < 0) { const char* e = getenv("LC3PLUS_ENC_NO_SPLIT"); split_off = e && e[0] == '1'; }
-      if (dy12 && !c->any_attack && !split_off) {
+    { if (split) {
         const int mc = c->big ? LC3D_MEMCAP_BIG : LC3D_MEMCAP_STD;
         const size_t ns = (size_t)c->ncs * n_frames * c->N, nr = (size_t)c->ncs * n_frames * FR_WORDS;
         if (c->spec_cap < ns) { if (c->d_spec) HIPCHK(hipFree(c->d_spec)); c->d_spec = nullptr; c->spec_cap = 0; HIPCHK(hipMalloc((void**)&c->d_spec, ns * sizeof(float))); c->spec_cap = ns; }
@@ -2874,8 +2904,14 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
         else hipLaunchKernelGGL(lc3_enc_front_kernel, dim3((unsigned)c->ncs * runs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames, c->ncs, dspec, dfrec, c->d_xnext);
         HIPCHK(hipGetLastError());
         const long long nfr = (long long)c->ncs * n_frames;
-        hipLaunchKernelGGL(lc3_enc_snsvq_kernel, dim3((unsigned)((nfr + WAVE - 1) / WAVE)), dim3(WAVE), 0, s, c->d_plan, dfrec, nfr);
+        if (c->any_attack) {
+            const int mcs = c->big ? LC3D_MEMCAP_BIG : LC3D_MEMCAP_STD;
+            hipLaunchKernelGGL(lc3_enc_attack_kernel, dim3((unsigned)((c->ncs + WAVE - 1) / WAVE)), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, c->state_words, LC3D_ST_SCAL(mcs), dfrec, n_frames, c->ncs);
+            HIPCHK(hipGetLastError());
+        }
+        hipLaunchKernelGGL(lc3_enc_snsvq_kernel, dim3((unsigned)((nfr + WAVE - 1) / WAVE)), dim3(WAVE), 0, s, c->d_plan, dfrec, nfr, c->any_attack);
         HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
       } }
     if (c->big) hipLaunchKernelGGL(lc3_encode_kernel_big, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames,
                                    dout, out_stride, c->ncs, dtr, ddump, dstride, dy12, c->d_status, dT, dt0, dspec, dfrec, c->d_xnext);
@@ -3040,6 +3076,7 @@ extern "C" int lc3hip_destroy(void* ctx)
         if (c->ev_k[i]) hipEventDestroy(c->ev_k[i]);
     }
     if (c->s_h2d) hipStreamDestroy(c->s_h2d);
+    if (c->s_pre) { hipStreamDestroy(c->s_pre); hipEventDestroy(c->ev_fork); hipEventDestroy(c->ev_join); }
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); }

@@ -75,6 +75,9 @@ typedef struct {
 #define FR_SCFQ  16                      /* 16 floats: quantised scale factors (R/sns_quantize_scf.c) */
 #define FR_IDX   32                      /* 7 ints: the SNS indices */
 #define FR_BW    39                      /* int: bandwidth index (R/detect_cutoff_warped.c) */
+#define FR_ATT   40                      /* attack detector (R/attack_detector.c): 4 block energies, [44..45] the filter memory after this frame, [46] the flag (lc3_enc_attack_kernel) */
+#define FR_ATTM  44
+#define FR_ATTFLAG 46
 #define FR_WORDS 48
 
 /* per channel-frame status bits of the encoder: conditions the reference only asserts on (SURVEY 5 "failure detection") */

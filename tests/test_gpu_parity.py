@@ -466,3 +466,39 @@ def test_host_pipeline_matches_device_path():
         h2 = alloc((B, T - 24, 480), np.int16); h2[:] = pcm[:, 24:]; o2 = alloc((B, T - 24, 80), np.uint8)
         b.encode_host(h1, o1); b.encode_host(h2, o2)
         assert (o1 == want[:, :24]).all() and (o2 == want[:, 24:]).all(), pinned
+
+
+def test_attack_detector_on_the_split_path():
+    """Streams with attack handling (48 kHz / 10 ms at 100 ... 339 bytes, 32 kHz from 81 bytes: R/setup_enc_lc3.c:288-307) on the path
+    where the detector's block energies come from the frame-parallel front kernel, its decision from lc3_enc_attack_kernel and the
+    scale-factor smoothing from the quantiser's kernel: transient-heavy PCM, several launches (the detector's state crosses them), and
+    a bitrate switch that turns attack handling off and on again (the reset rule)."""
+    amd = _amd()
+    rng = np.random.default_rng(5)
+    B, T = 96, 36
+    pcm = synth_pcm(B, T, 480, 48000, seed=1234).astype(np.float64)
+    for s in range(B):                                   # bursts: silence then full-scale noise, at random frames
+        for t in rng.choice(T, size=5, replace=False):
+            a0 = t * 480 + int(rng.integers(0, 400))
+            flat = pcm[s].reshape(-1)
+            flat[max(0, a0 - 960):a0] *= 0.01
+            flat[a0:a0 + 300] = rng.uniform(-30000, 30000, size=flat[a0:a0 + 300].shape)
+    pcm = np.clip(np.rint(pcm), -32768, 32767).astype(np.int16)
+    rates = [80000, 96000, 128000, 192000, 256000, 64000]
+    br = [rates[i % len(rates)] for i in range(B)]
+    b = amd.Batch(B, 48000, 1, 10.0, 0, br, device=0)
+    got = np.concatenate([b.encode(pcm[:, :9]), b.encode(pcm[:, 9:20]), b.encode(pcm[:, 20:])], axis=1)
+    want = _oracle_batch(pcm, 48000, 10.0, 0, br, b.stride)
+    nb = np.array([b.num_bytes(i) for i in range(B)])
+    bad = [(i, t) for i in range(B) for t in range(T) if (got[i, t, :nb[i]] != want[i, t, :nb[i]]).any()]
+    assert not bad, (len(bad), bad[:8])
+    # attack handling on -> off -> on across bitrate switches, 6-frame launches
+    o = Oracle(48000, 1, 10.0, 0, 96000, portable_math=True)
+    b = amd.Batch(1, 48000, 1, 10.0, 0, [96000], device=0)
+    sched = {0: 96000, 12: 32000, 24: 128000}
+    for t0 in range(0, T, 6):
+        if t0 in sched:
+            assert b.set_bitrate(0, sched[t0]) == 0 and o.set_bitrate(sched[t0]) == 0
+        g = b.encode(pcm[3:4, t0:t0 + 6])
+        for k in range(6):
+            assert (g[0, k, :o.nbytes] == o.encode(pcm[3, t0 + k][None])).all(), (t0, k)
