@@ -2775,7 +2775,7 @@ struct lc3hip_ctx {
     hipStream_t stream, last_stream; hipEvent_t ev0, ev1; float last_ms;
 };
 
-#define LC3D_FUSED_MAX_T 4
+#define LC3D_FUSED_MAX_T 8
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "lc3plus_hip: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); return 1; } } while (0)
 /* inside the create functions: release what has been allocated so far (the caller only sees ctx == NULL) */
 #define HIPCHK_OR(x, cleanup) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "lc3plus_hip: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); cleanup; return 1; } } while (0)
