@@ -1135,7 +1135,7 @@ static void ac_shift(bitw_t* w)                                 /* R/ari_codec.c
         while (w->carry_count > 0) { w->p[w->bp] = (w->carry + 255) & 255; w->bp++; w->carry_count--; }
         w->cache = w->low >> 16; w->carry = 0;
     } else w->carry_count++;
-    w->low = (w->low << 8) & 0xFFFFFF;
+    w->low = (int)(((unsigned)w->low << 8) & 0xFFFFFFu);       /* unsigned: the reference's int shift overflows for low >= 2^23 */
 }
 static void ac_encode(bitw_t* w, int freq, int cum)             /* R/ari_codec.c:511-529 */
 {
