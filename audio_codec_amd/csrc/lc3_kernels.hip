@@ -73,6 +73,7 @@
 /* LDS slice of one wave (~12.8 KB -> 12 waves per CU)                                                */
 /* ------------------------------------------------------------------------------------------------ */
 struct __attribute__((aligned(16))) WaveLds {
+    static constexpr int MISC = 368;   /* = SM_MISC: where the scratch vectors of this layout's sm[] start */
     float xbuf[MEMCAP + MAXN];  /* [MDCT/resampler memory right-aligned in 0..MEMCAP | current frame X]; once the MDCT fold has consumed the
                                    frame, X is scratch (DFT ping buffer, TNS output) and finally the quantised spectrum xq */
     float A[MAXN];              /* scratch, then the MDCT spectrum (shaped / TNS-filtered in place); the output frame during the bitstream stage */
@@ -90,6 +91,17 @@ struct __attribute__((aligned(16))) WaveLds {
 };
 static_assert(offsetof(lc3d_plan, tw1) == 4 * LC3D_PLAN_HEAD_WORDS, "plan head size");
 static_assert(offsetof(WaveLds, A) % 16 == 0 && (offsetof(WaveLds, sm) + (MAXN / 2 + 2) * 4) % 16 == 0 && offsetof(WaveLds, xbuf) == 0, "16-byte aligned LDS rows");
+/* the slice of lc3_enc_front_kernel: what the stateless front needs, nothing of the pitch buffers or the coder's work areas -> 6 KB, six waves per SIMD */
+struct __attribute__((aligned(16))) FrontLds {
+    static constexpr int MISC = 96;
+    float xbuf[MEMCAP + MAXN];
+    float A[MAXN];
+    float sm[160];              /* band energies [0..63], scale factors [64..79], scratch from MISC */
+    int   pc[LC3D_PLAN_HEAD_WORDS];
+    int   cc[14];
+    float fsc[12];
+    int   isc[56];
+};
 #define PI(f) uni(L.pc[offsetof(lc3d_plan, f) / 4])
 #define PF(f) __int_as_float(uni(L.pc[offsetof(lc3d_plan, f) / 4]))
 #define CI(f) uni(L.cc[offsetof(lc3d_chan, f) / 4])
@@ -671,7 +683,7 @@ STAGE void st_ltpf(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict_
 /* ---- attack detector: R/attack_detector.c:13-104 (only when attack_handling) ---- */
 /* first half (:26-77): decimation to 16 kHz, high-pass with the filter memory (m0, m1) of the previous frame, block energies: lane b < nb
  * returns block b's energy; (nm0, nm1) is the filter memory this frame leaves.  Stateless given the previous frame's last samples. */
-__device__ __forceinline__ float attack_energies(WaveLds& L, int lane, float m0, float m1, float& nm0, float& nm1)
+template <class LdsT> __device__ __forceinline__ float attack_energies(LdsT& L, int lane, float m0, float m1, float& nm0, float& nm1)
 {
     const int nb = PI(att_nblocks), n16 = nb * 40;
     const float* in = XCUR(L);
@@ -1027,7 +1039,7 @@ template <class LdsT> STAGE void mdct_dft60(const lc3d_plan* __restrict__ P, Lds
     }
 }
 
-STAGE void mdct_pre(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
+template <class LdsT> STAGE void mdct_pre(const lc3d_plan* __restrict__ P, LdsT& L, int lane)
 {
     const int N = PI(N), h = N >> 1, la = PI(la), ml = N - la;
     const float* w = &lc3t_win_pool[PI(win_off)];
@@ -1055,7 +1067,7 @@ STAGE void mdct_pre(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
     LSYNC();
 }
 /* post-twiddle (leaf stage) */
-STAGE void mdct_post(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
+template <class LdsT> STAGE void mdct_post(const lc3d_plan* __restrict__ P, LdsT& L, int lane)
 {
     const int N = PI(N), h = N >> 1;
     const float norm = PF(dct4_norm);
@@ -1084,7 +1096,7 @@ STAGE void mdct_post(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
 /* ------------------------------------------------------------------------------------------------ */
 
 /* ---- per-band energy R/per_band_energy.c:13-30, bandwidth detector R/detect_cutoff_warped.c:13-83 ---- */
-STAGE void st_energy_bw(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
+template <class LdsT> STAGE void st_energy_bw(const lc3d_plan* __restrict__ P, LdsT& L, int lane)
 {
     const uint16_t* be = &lc3t_band_pool[PI(band_off)];
     float* en = &L.sm[SM_ENER];
@@ -1129,7 +1141,7 @@ STAGE void st_energy_bw(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
 }
 
 /* ---- SNS scale factors R/sns_compute_scf.c:13-176 ---- */
-STAGE void st_sns_scf(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
+template <class LdsT> STAGE void st_sns_scf(const lc3d_plan* __restrict__ P, LdsT& L, int lane)
 {
     float* x = &L.sm[SM_ENER];
     const int smooth = uni(L.isc[I_ATT_FLAG]);
@@ -1157,7 +1169,7 @@ STAGE void st_sns_scf(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
     nf = nf > PF(c_2m32) ? nf : PF(c_2m32);
     if (s < nf) s = nf;
     const float xl = (float)((double)m_log2f(s) / 2.0);
-    float* tmp = &L.sm[SM_MISC];
+    float* tmp = &L.sm[LdsT::MISC];
     LSYNC();
     x[lane] = s;                                    /* the reference overwrites the energies in place */
     tmp[lane] = xl;
