@@ -1602,39 +1602,34 @@ STAGE int tns_levinson(WaveLds& L, int lane, int nf, int maxOrder, float maxPG)
  * bits the filters add (flags included). */
 STAGE int tns_quant(WaveLds& L, int lane, int nf, int maxOrder, int obits_off, int codes)
 {
-    const int f = lane >> 5, l5 = lane & 31;
+    /* lane i < 8 of half f owns reflection coefficient i of filter f: its interval among the 17 (R/tns_coder.c:157-168 findRC_idx: the
+     * intervals (thr[q], thr[q+1]] are disjoint, none -> 0), its quantised value, its Huffman bits; order = last non-zero coefficient
+     * (ballot), bit count = row sum */
+    const int f = lane >> 5, i = lane & 31;
     const int code = (codes >> (2 * f)) & 3;
-    const bool live = f < nf;
+    const bool live = f < nf, mine = live && i < maxOrder && i < 8;
     float* rcs = TNS_RCS(L, f);
     const float* sc = TNS_SC(L, f);
-    float rc[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) rc[i] = (i < maxOrder && live) ? sc[(code == 2 ? 9 : 46) + i] : 0.0f;
+    const float rc = mine ? sc[(code == 2 ? 9 : 46) + i] : 0.0f;
     int tns = live && code != 0;
-    int bits = live ? 1 : 0, ord = 0; int idxq[8];
-    {   /* R/tns_coder.c:157-168 findRC_idx: lane q of a half tests its interval (thr[q], thr[q+1]] for every coefficient; the
-         * intervals are disjoint, so each half of the ballot has at most one bit set (none -> 0, as in the reference) */
-        const float tlo = lc3t_tns_rc_thr[l5 < 17 ? l5 : 0], thi = lc3t_tns_rc_thr[l5 < 17 ? l5 + 1 : 1];
+    int idx = 0;
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const unsigned long long hit = __ballot(l5 < 17 && rc[i] <= thi && rc[i] > tlo);
-            const unsigned hh = f ? (unsigned)(hit >> 32) : (unsigned)hit;
-            idxq[i] = (i < maxOrder && hh) ? 31 - __clz((int)hh) : 0;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 8; i++) { const float q = (i < maxOrder && tns) ? lc3t_tns_rc_pts[idxq[i]] : 0.0f; rc[i] = q; if (i < maxOrder && q != 0) ord = i + 1; }
+    for (int q = 0; q < 17; q++) idx = (rc <= lc3t_tns_rc_thr[q + 1] && rc > lc3t_tns_rc_thr[q]) ? q : idx;
+    if (!mine) idx = 0;
+    const float qv = (mine && tns) ? lc3t_tns_rc_pts[idx] : 0.0f;
+    const unsigned long long nzm = __ballot(qv != 0);
+    const unsigned nzh = (f ? (unsigned)(nzm >> 32) : (unsigned)nzm) & 0xFFu;
+    const int ord = nzh ? 32 - __clz((int)nzh) : 0;
     if (ord == 0) tns = 0;            /* would be undefined behaviour in the reference (R/tns_coder.c:311-321); filter off */
-    if (tns) {
-        int tmp = lc3t_tns_order_bits[obits_off + ord - 1];
-#pragma unroll
-        for (int i = 0; i < 8; i++) if (i < ord) tmp += lc3t_tns_coef_bits[i * 17 + idxq[i]];
-        bits += (tmp + 2047) >> 11;
-    }
-    if (l5 == 0 && live) {
-        L.isc[I_TNS_ORD0 + f] = tns ? ord : 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) { if (tns && i < ord) L.isc[I_TNS_IDX0 + f * 8 + i] = idxq[i]; rcs[i] = rc[i]; }
+    int term = (tns && i < ord && i < 8) ? lc3t_tns_coef_bits[i * 17 + idx] : 0;
+    term += dpp_i<DPP_SHR1>(0, term); term += dpp_i<DPP_SHR2>(0, term); term += dpp_i<DPP_SHR4>(0, term);      /* lane 7 of the row: coefficients 0..7 */
+    const int tsum = __builtin_amdgcn_readlane(term, 7), tsum1 = __builtin_amdgcn_readlane(term, 39);
+    int bits = live ? 1 : 0;
+    if (tns) bits += ((f ? tsum1 : tsum) + lc3t_tns_order_bits[obits_off + ord - 1] + 2047) >> 11;
+    if (live && i < 8) {
+        rcs[i] = qv;
+        if (tns && i < ord) L.isc[I_TNS_IDX0 + f * 8 + i] = idx;
+        if (i == 0) L.isc[I_TNS_ORD0 + f] = tns ? ord : 0;
     }
     LSYNC();
     return __builtin_amdgcn_readlane(bits, 0) + __builtin_amdgcn_readlane(bits, 32);
