@@ -1046,23 +1046,32 @@ template <class LdsT> STAGE void mdct_pre(const lc3d_plan* __restrict__ P, LdsT&
     const float* t = &L.xbuf[MEMCAP - ml];          /* t[j] = [memory | frame], j < 2N-la ; zero beyond */
     float* X = XCUR(L);
     const int lim = 2 * N - la;
-    for (int i = lane; i < h; i += WAVE) {          /* window + fold (R/mdct.c:113-119) -> A */
-        const int j0 = 3 * h - i - 1, j1 = 3 * h + i, j2 = i, j3 = 2 * h - i - 1;
-        const float a0 = (j0 < lim ? t[j0] : 0.0f) * w[j0];
-        const float a1 = (j1 < lim ? t[j1] : 0.0f) * w[j1];
-        const float a2 = t[j2] * w[j2];
-        const float a3 = t[j3] * w[j3];
-        L.A[i] = -a0 - a1;
-        L.A[h + i] = a2 - a3;
+    constexpr int NK = (MAXN / 2 + WAVE - 1) / WAVE;    /* unrolled with a compile-time bound: the window / twiddle loads of all rounds are in flight together */
+#pragma unroll
+    for (int k = 0; k < NK; k++) {                  /* window + fold (R/mdct.c:113-119) -> A */
+        const int i = lane + 64 * k;
+        if (i < h) {
+            const int j0 = 3 * h - i - 1, j1 = 3 * h + i, j2 = i, j3 = 2 * h - i - 1;
+            const float a0 = (j0 < lim ? t[j0] : 0.0f) * w[j0];
+            const float a1 = (j1 < lim ? t[j1] : 0.0f) * w[j1];
+            const float a2 = t[j2] * w[j2];
+            const float a3 = t[j3] * w[j3];
+            L.A[i] = -a0 - a1;
+            L.A[h + i] = a2 - a3;
+        }
     }
     LSYNC();
     /* the frame's tail becomes the next frame's MDCT / resampler memory; the frame half of xbuf (X) is scratch from here on */
     for (int i = lane; i < ml; i += WAVE) L.xbuf[MEMCAP - ml + i] = L.xbuf[MEMCAP + N - ml + i];
     LSYNC();
-    for (int i = lane; i < h; i += WAVE) {          /* pre-twiddle R/dct4.c:84-86: A -> X */
-        const float ar = L.A[2 * i], ai = L.A[N - 2 * i - 1], br = P->tw1[2 * i], bi = P->tw1[2 * i + 1];
-        X[2 * i] = ar * br - ai * bi;
-        X[2 * i + 1] = ai * br + ar * bi;
+#pragma unroll
+    for (int k = 0; k < NK; k++) {                  /* pre-twiddle R/dct4.c:84-86: A -> X */
+        const int i = lane + 64 * k;
+        if (i < h) {
+            const float ar = L.A[2 * i], ai = L.A[N - 2 * i - 1], br = P->tw1[2 * i], bi = P->tw1[2 * i + 1];
+            X[2 * i] = ar * br - ai * bi;
+            X[2 * i + 1] = ai * br + ar * bi;
+        }
     }
     LSYNC();
 }
@@ -1446,7 +1455,8 @@ STAGE void st_sns_vq(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
 }
 
 /* ---- SNS interpolation R/sns_interpolate_scf.c:13-89 and spectral shaping R/mdct_shaping.c:13-22 ---- */
-STAGE void st_sns_apply(const lc3d_plan* __restrict__ P, WaveLds& L, int lane, const float* src /* the MDCT spectrum: L.A, or where the front kernel's copy was parked */)
+STAGE void st_sns_apply(const lc3d_plan* __restrict__ P, WaveLds& L, int lane, const float* src /* the MDCT spectrum: L.A, or where the front kernel's copy was parked */,
+                        unsigned bob0, unsigned bob1, unsigned bob2, unsigned bob3 /* band index of bin lane + 64 k in byte k: constant for the launch, fetched once */)
 {
     const float* g = &L.sm[SM_SCFQ];
     float* gi = &L.sm[SM_GI];
@@ -1482,10 +1492,15 @@ STAGE void st_sns_apply(const lc3d_plan* __restrict__ P, WaveLds& L, int lane, c
     }
     if (lane < nb) gi[lane] = m_pow2f(-v);
     LSYNC();
-    for (int j = lane; j < PI(N); j += WAVE) {
-        const int b = P->band_of_bin[j];
-        const float x = src[j];
-        L.A[j] = b < nb ? x * gi[b] : x;
+    const unsigned bob[4] = {bob0, bob1, bob2, bob3};
+#pragma unroll
+    for (int k = 0; k < (MAXN + WAVE - 1) / WAVE; k++) {
+        const int j = lane + 64 * k;
+        if (j < PI(N)) {
+            const int b = (int)((bob[k >> 2] >> (8 * (k & 3))) & 255u);
+            const float x = src[j];
+            L.A[j] = b < nb ? x * gi[b] : x;
+        }
     }
     LSYNC();
 }
@@ -2554,6 +2569,9 @@ KERNEL_NAME(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans
     const bool fast16 = bitdepth == 16 && (N & 7) == 0 && N <= 8 * WAVE && ((((size_t)pcm) + (((size_t)strm * T) * channels + ch) * N * 2) & 15) == 0 && ((N * 2 * channels) & 15) == 0;
     uint4 nv = make_uint4(0, 0, 0, 0); float ny0 = 0, ny1 = 0;
     constexpr int SPK = (MAXN + WAVE - 1) / WAVE;
+    unsigned bob[4] = {0, 0, 0, 0};                  /* band of this lane's bins (lane + 64 k), one byte each: the table look-up of the SNS shaping, once per launch */
+#pragma unroll
+    for (int k = 0; k < SPK; k++) { const int j = lane + 64 * k; bob[k >> 2] |= (unsigned)(j < N ? P->band_of_bin[j] : 255) << (8 * (k & 3)); }
     float sp[SPK]; float rq = 0; int ri = 0;
 #pragma unroll
     for (int k = 0; k < SPK; k++) sp[k] = 0;
@@ -2650,7 +2668,7 @@ KERNEL_NAME(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans
         st_sns_vq(P, L, lane);
         TICK(8);
         }
-        st_sns_apply(P, L, lane, spec ? XCUR(L) : L.A);
+        st_sns_apply(P, L, lane, spec ? XCUR(L) : L.A, bob[0], bob[1], bob[2], bob[3]);
         TICK(9);
         if (tr) { if (lane < 16) tr->scf_q[lane] = L.sm[SM_SCFQ + lane]; if (lane < 7) tr->scf_idx[lane] = L.isc[I_SCF0 + lane];
                   for (int i = lane; i < N; i += WAVE) tr->spec_shaped[i] = L.A[i]; }
