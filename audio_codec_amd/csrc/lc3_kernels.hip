@@ -1836,7 +1836,8 @@ STAGE void st_gain_estimate(const lc3d_plan* __restrict__ P, const lc3d_chan* __
     mem_target = nbitsSQ;
     nbitsSQ = (int)((double)nbitsSQ + round((double)tbits_off));
     float xm = 0;
-    for (int i = lane; i < lg; i += WAVE) xm = fmaxf(xm, fabsf(L.A[i]));
+#pragma unroll
+    for (int k = 0; k < MAXN / WAVE + 1; k++) { const int i = lane + 64 * k; if (i < lg) xm = fmaxf(xm, fabsf(L.A[i])); }
     const float x_max = unif(wave_max_f(xm));
     float reg_val = 0;
     if (PI(hrmode) && CI(reg_bits) > 0) {
@@ -1934,17 +1935,23 @@ STAGE void st_quantize(const lc3d_plan* __restrict__ P, const lc3d_chan* __restr
     const float gain = unif(L.fsc[F_GAIN]);
     int* xq = XQ(L); uint32_t* cdw = CDW(L);
     SUB_BEGIN();
-    for (int i = lane; i < nt; i += WAVE) {
-        const float x = L.A[i];
-        const int sg = x > 0 ? 1 : x < 0 ? -1 : 0;
-        xq[i] = (int)truncf(x / gain + offs * (float)sg);
+    /* compile-time loop bound: the (long) division sequences of a lane's lines are independent and interleave */
+#pragma unroll
+    for (int k = 0; k < MAXN / WAVE + 1; k++) {
+        const int i = lane + 64 * k;
+        if (i < nt) {
+            const float x = L.A[i];
+            const int sg = x > 0 ? 1 : x < 0 ? -1 : 0;
+            xq[i] = (int)truncf(x / gain + offs * (float)sg);
+        }
     }
     int rate = 0;
     if ((fs < 48000 && tb > 320 + (fs / 8000 - 2) * 160) || (fs == 48000 && tb > 800)) rate = 512;
     if (mode == 0 && ((fs < 48000 && tb >= 640 + (fs / 8000 - 2) * 160) || (fs == 48000 && tb >= 1120))) mode = 1;
     LSYNC();
     int lp = 0;
-    for (int p = lane; p < (nt >> 1); p += WAVE) if (p >= 1 && (xq[2 * p] != 0 || xq[2 * p + 1] != 0)) lp = p;
+#pragma unroll
+    for (int k = 0; k < MAXN / 2 / WAVE + 1; k++) { const int p = lane + 64 * k; if (p < (nt >> 1) && p >= 1 && (xq[2 * p] != 0 || xq[2 * p + 1] != 0)) lp = p; }
     lp = uni(wave_max_i(lp));
     const int lastnz = lp >= 1 ? 2 * lp + 1 : 1;
     const int ntup = (lastnz + 1) >> 1;
