@@ -74,6 +74,7 @@
 /* ------------------------------------------------------------------------------------------------ */
 struct __attribute__((aligned(16))) WaveLds {
     static constexpr int MISC = 368;   /* = SM_MISC: where the scratch vectors of this layout's sm[] start */
+    static constexpr int XOFF = MEMCAP; /* the frame half of xbuf (XCUR / XQ) */
     float xbuf[MEMCAP + MAXN];  /* [MDCT/resampler memory right-aligned in 0..MEMCAP | current frame X]; once the MDCT fold has consumed the
                                    frame, X is scratch (DFT ping buffer, TNS output) and finally the quantised spectrum xq */
     float A[MAXN];              /* scratch, then the MDCT spectrum (shaped / TNS-filtered in place); the output frame during the bitstream stage */
@@ -94,6 +95,7 @@ static_assert(offsetof(WaveLds, A) % 16 == 0 && (offsetof(WaveLds, sm) + (MAXN /
 /* the slice of lc3_enc_front_kernel: what the stateless front needs, nothing of the pitch buffers or the coder's work areas -> 6 KB, six waves per SIMD */
 struct __attribute__((aligned(16))) FrontLds {
     static constexpr int MISC = 96;
+    static constexpr int XOFF = MEMCAP;
     float xbuf[MEMCAP + MAXN];
     float A[MAXN];
     float sm[160];              /* band energies [0..63], scale factors [64..79], scratch from MISC */
@@ -101,12 +103,15 @@ struct __attribute__((aligned(16))) FrontLds {
     int   cc[14];
     float fsc[12];
     int   isc[56];
+#ifdef LC3_STAGE_TIMING
+    long long tacc[NSTAGE];
+#endif
 };
 #define PI(f) uni(L.pc[offsetof(lc3d_plan, f) / 4])
 #define PF(f) __int_as_float(uni(L.pc[offsetof(lc3d_plan, f) / 4]))
 #define CI(f) uni(L.cc[offsetof(lc3d_chan, f) / 4])
-#define XCUR(L) (&(L).xbuf[MEMCAP])
-#define XQ(L)   ((int*)&(L).xbuf[MEMCAP])
+#define XCUR(L) (&(L).xbuf[(L).XOFF])
+#define XQ(L)   ((int*)&(L).xbuf[(L).XOFF])
 #define SPEC(L) ((L).A)
 #define BYTES(L) ((uint8_t*)(L).A)            /* up to 640 bytes, valid from the bitstream stage to the copy-out */
 #define CDW(L)  ((uint32_t*)&(L).sm[0])      /* per 2-tuple: ctx(10) | maxlev+1 (6) | pki of the final symbol (6) | sym (5) */
@@ -384,7 +389,7 @@ __device__ __forceinline__ double rl_d(double v, int l)
 /* ------------------------------------------------------------------------------------------------ */
 
 /* ---- 12.8 kHz resampler + 50 Hz high-pass: R/resamp12k8.c:13-84.  Appends len12 samples to h12. ---- */
-STAGE void st_resample(const lc3d_plan* __restrict__ P, WaveLds& L, int lane, const float* __restrict__ yin /* the frame's HP-filtered 12.8 kHz samples from the pre-kernels, or null */)
+template <class LdsT> STAGE void st_resample(const lc3d_plan* __restrict__ P, LdsT& L, int lane, const float* __restrict__ yin /* the frame's HP-filtered 12.8 kHz samples from the pre-kernels, or null */)
 {
     const int mlen = PI(rs_mem_in_len), stride = PI(rs_stride), n12 = PI(n12), len12 = PI(len12), N = PI(N);
     const float sf = PF(rs_scale);
@@ -496,7 +501,7 @@ __device__ __forceinline__ float lane_serial_sum(const float* base, int stride, 
 
 /* normalised correlations at lags T_a and T_b over acf <= 64 samples (R/olpa.c:104-114), both at once: five serial sums
  * (ab_a, bb_a, aa, ab_b, bb_b) in five lanes, products parked in LDS scratch (A) */
-__device__ __forceinline__ void olpa_normcorr2(WaveLds& L, const float* s6, int acf, int Ta, int Tb, int lane, float eps, float& nca, float& ncb)
+template <class LdsT> __device__ __forceinline__ void olpa_normcorr2(LdsT& L, const float* s6, int acf, int Ta, int Tb, int lane, float eps, float& nca, float& ncb)
 {
     float* pr = L.A;
     if (lane < acf) {
@@ -512,7 +517,7 @@ __device__ __forceinline__ void olpa_normcorr2(WaveLds& L, const float* s6, int 
 }
 
 /* ---- open-loop pitch: R/olpa.c:52-143 ---- */
-STAGE void st_olpa(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
+template <class LdsT> STAGE void st_olpa(const lc3d_plan* __restrict__ P, LdsT& L, int lane)
 {
     const int len = PI(len12), len2 = len >> 1;
     SUB_BEGIN();
@@ -537,7 +542,7 @@ STAGE void st_olpa(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
     LSYNC();
     SUB(25);
     const float* s6 = &L.h6[194 - len2 - back];
-    float* R0 = &L.sm[SM_MISC];                     /* 98 unweighted autocorrelations */
+    float* R0 = &L.sm[L.MISC];                     /* 98 unweighted autocorrelations */
     const bool two = lane < 34;
     const float* q0 = s6 - (17 + lane); const float* q1 = s6 - (two ? 81 + lane : 17 + lane);
     float r0 = 0, r1 = 0;
@@ -565,7 +570,7 @@ STAGE void st_olpa(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
 }
 
 /* ---- LTPF parameter coder: R/ltpf_coder.c:34-263 ---- */
-STAGE void st_ltpf(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ C, WaveLds& L, int lane)
+template <class LdsT> STAGE void st_ltpf(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ C, LdsT& L, int lane)
 {
     const int len = PI(len12);                 /* N of the reference = xLen - 1 */
     const float* x = &L.h12[384 - len - 24];
@@ -592,8 +597,8 @@ STAGE void st_ltpf(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict_
             sum1 = rl_f(acc, 0); sum2 = rl_f(acc, 1);
             LSYNC();
         }
-        float* cor = &L.sm[SM_MISC];           /* up to 17 */
-        float* cor_int = &L.sm[SM_MISC + 32];  /* up to 36 */
+        float* cor = &L.sm[L.MISC];           /* up to 17 */
+        float* cor_int = &L.sm[L.MISC + 32];  /* up to 36 */
         if (lane < nl) {
             const int lag = t_min + lane;
             const float* xl = x - lag;
@@ -730,7 +735,7 @@ __device__ __forceinline__ void attack_decide(float e0, float e1, float e2, floa
     if (last_pos > hang) flag = 1;
     last_pos = pos;
 }
-STAGE void st_attack(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
+template <class LdsT> STAGE void st_attack(const lc3d_plan* __restrict__ P, LdsT& L, int lane)
 {
     float nm0, nm1;
     const float e = attack_energies(L, lane, unif(L.fsc[F_ATT_M0]), unif(L.fsc[F_ATT_M1]), nm0, nm1);
@@ -1223,7 +1228,7 @@ template <class LdsT> STAGE void st_sns_scf(const lc3d_plan* __restrict__ P, Lds
  * (a float cross-multiplication, not a total order, so it cannot become a tree reduction) is replayed by every lane over the
  * row's (a, b) pairs read back from LDS - 6 VALU per candidate instead of 10, for four searches at once.  Dimensions beyond a
  * search's N carry |x| = 0 and b = +INF: a*cden > INF*cnum is false for every cnum >= 0, and cnum >= 0 from candidate 0 on. */
-__device__ __forceinline__ void pvq_search_rows(WaveLds& L, int lane, const float* tgt, float* pv)
+template <class LdsT> __device__ __forceinline__ void pvq_search_rows(LdsT& L, int lane, const float* tgt, float* pv)
 {
     const int s = lane >> 4, i = lane & 15;
     const int dim = s == 0 ? 10 : s == 1 ? 6 : 16, K = s == 0 ? 10 : s == 1 ? 1 : s == 2 ? 8 : 6;
@@ -1322,7 +1327,7 @@ __device__ __forceinline__ void mpvq_index_rows(const int* pulses, int lane, int
 }
 
 /* ---- SNS vector quantiser R/sns_quantize_scf.c:165-430 (+ DCT-II(16) R/dct4.c:28-48, IDCT-II :19-41) ---- */
-STAGE void st_sns_vq(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
+template <class LdsT> STAGE void st_sns_vq(const lc3d_plan* __restrict__ P, LdsT& L, int lane)
 {
     const float* env = &L.sm[SM_SCF];
     float* st1 = &L.sm[SM_ST1]; float* tgt = &L.sm[SM_TGT]; float* tgtp = &L.sm[SM_TGTP];
@@ -1455,7 +1460,7 @@ STAGE void st_sns_vq(const lc3d_plan* __restrict__ P, WaveLds& L, int lane)
 }
 
 /* ---- SNS interpolation R/sns_interpolate_scf.c:13-89 and spectral shaping R/mdct_shaping.c:13-22 ---- */
-STAGE void st_sns_apply(const lc3d_plan* __restrict__ P, WaveLds& L, int lane, const float* src /* the MDCT spectrum: L.A, or where the front kernel's copy was parked */,
+template <class LdsT> STAGE void st_sns_apply(const lc3d_plan* __restrict__ P, LdsT& L, int lane, const float* src /* the MDCT spectrum: L.A, or where the front kernel's copy was parked */,
                         unsigned bob0, unsigned bob1, unsigned bob2, unsigned bob3 /* band index of bin lane + 64 k in byte k: constant for the launch, fetched once */)
 {
     const float* g = &L.sm[SM_SCFQ];
@@ -1510,7 +1515,7 @@ STAGE void st_sns_apply(const lc3d_plan* __restrict__ P, WaveLds& L, int lane, c
 /* ------------------------------------------------------------------------------------------------ */
 struct TnsGeom { int numfilters, maxOrder, nSub, start0, start1, stop0, stop1; float maxPG; int obits_off; };   /* scalars only: no stack object */
 
-__device__ __forceinline__ TnsGeom tns_geom(WaveLds& L, int bw_idx, int bw_bin)
+template <class LdsT> __device__ __forceinline__ TnsGeom tns_geom(LdsT& L, int bw_idx, int bw_bin)
 {
     TnsGeom g;
     int fs = PI(fs), N = PI(N); const int nBits = CI(total_bits), dms = PI(dms);
@@ -1533,7 +1538,7 @@ __device__ __forceinline__ TnsGeom tns_geom(WaveLds& L, int bw_idx, int bw_bin)
 #define TNS_SC(L, f)  (&(L).sm[(f) ? SM_PVQ : SM_MISC + 112])
 #define TNS_RCS(L, f) (&(L).sm[(f) ? SM_PVQ + 64 : SM_MISC + 104])
 
-STAGE void tns_lpc_weight(WaveLds& L, int lane, int f, int maxOrder, float maxPG, float predGain)
+template <class LdsT> STAGE void tns_lpc_weight(LdsT& L, int lane, int f, int maxOrder, float maxPG, float predGain)
 {
     float* sc = TNS_SC(L, f);
     if (lane == 0) {
@@ -1570,7 +1575,7 @@ STAGE void tns_lpc_weight(WaveLds& L, int lane, int f, int maxOrder, float maxPG
 /* Levinson-Durbin (R/tns_coder.c:41-89) and prediction gain; the two filters are independent up to here, so lane f runs filter f
  * (fully unrolled for register residency).  Code 0: filter off, 1: on, 2: on and LPC weighting required; lane f leaves a[] at
  * sc[36..], rc[] at sc[46..], predGain at sc[63] of its filter's scratch.  Returns code0 | code1 << 2. */
-STAGE int tns_levinson(WaveLds& L, int lane, int nf, int maxOrder, float maxPG)
+template <class LdsT> STAGE int tns_levinson(LdsT& L, int lane, int nf, int maxOrder, float maxPG)
 {
     const int f = lane & 1;
     const float* racc = &L.sm[SM_MISC + 64 + f * 9];
@@ -1615,7 +1620,7 @@ STAGE int tns_levinson(WaveLds& L, int lane, int nf, int maxOrder, float maxPG)
 /* reflection-coefficient quantisation, order and bit count (R/tns_coder.c:289-336) of both filters: lanes 0-31 serve filter 0,
  * lanes 32-63 filter 1; `codes` from tns_levinson.  Results: quantised rc -> TNS_RCS(f), order / indices -> isc.  Returns the
  * bits the filters add (flags included). */
-STAGE int tns_quant(WaveLds& L, int lane, int nf, int maxOrder, int obits_off, int codes)
+template <class LdsT> STAGE int tns_quant(LdsT& L, int lane, int nf, int maxOrder, int obits_off, int codes)
 {
     /* lane i < 8 of half f owns reflection coefficient i of filter f: its interval among the 17 (R/tns_coder.c:157-168 findRC_idx: the
      * intervals (thr[q], thr[q+1]] are disjoint, none -> 0), its quantised value, its Huffman bits; order = last non-zero coefficient
@@ -1652,7 +1657,7 @@ STAGE int tns_quant(WaveLds& L, int lane, int nf, int maxOrder, int obits_off, i
 
 /* Lattice MA filter of one TNS filter (R/tns_coder.c:339-357), lane-parallel with exact replay: each lane owns a run of
  * consecutive bins and first replays the 8 preceding inputs; bins before the filter start come from the carried state. */
-STAGE void tns_lattice(WaveLds& L, int lane, int f, int b_first, int cnt, int ord)
+template <class LdsT> STAGE void tns_lattice(LdsT& L, int lane, int f, int b_first, int cnt, int ord)
 {
     float* stt = &L.sm[SM_MISC + 96];
     const float* rcs = TNS_RCS(L, f);
@@ -1689,7 +1694,7 @@ STAGE void tns_lattice(WaveLds& L, int lane, int f, int b_first, int cnt, int or
 }
 
 /* sub-division autocorrelations and the lag-windowed r[f][0..8] of both filters (R/tns_coder.c:258-281) */
-STAGE void tns_sums(WaveLds& L, int lane, int bw_idx, int bw_bin)
+template <class LdsT> STAGE void tns_sums(LdsT& L, int lane, int bw_idx, int bw_bin)
 {
     const TnsGeom G = tns_geom(L, bw_idx, bw_bin);
     float* racc = &L.sm[SM_MISC];              /* [f][sub][k] 2*3*9 = 54, sub-division energies 6 at +54, r[f][9] at +64 */
@@ -1749,7 +1754,7 @@ STAGE void tns_sums(WaveLds& L, int lane, int bw_idx, int bw_bin)
 
 /* TNS driver, inlined into the kernel so that the STAGE functions stay leaf calls (a nested call level makes the callee
  * save registers to scratch, i.e. HBM write traffic that is not part of the algorithm) */
-__device__ __forceinline__ void st_tns(const lc3d_plan* __restrict__ P, WaveLds& L, int lane, int bw_idx, int bw_bin)
+template <class LdsT> __device__ __forceinline__ void st_tns(const lc3d_plan* __restrict__ P, LdsT& L, int lane, int bw_idx, int bw_bin)
 {
     SUB_BEGIN();
     tns_sums(L, lane, bw_idx, bw_bin);
@@ -1821,7 +1826,7 @@ __device__ __forceinline__ bool gain_probe(float thr7, float thr50, const float*
 }
 
 /* ---- global gain estimate R/estimate_global_gain.c:30-137 ---- */
-STAGE void st_gain_estimate(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ C, WaveLds& L, int lane, int nbitsSQ)
+template <class LdsT> STAGE void st_gain_estimate(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ C, LdsT& L, int lane, int nbitsSQ)
 {
     const int lg = PI(ylen), off = CI(gg_off), nq = lg >> 2;
     SUB_BEGIN();
@@ -1928,7 +1933,7 @@ STAGE void st_gain_estimate(const lc3d_plan* __restrict__ P, const lc3d_chan* __
 }
 
 /* ---- quantisation + exact bit estimate R/quantize_spec.c:26-197 ---- */
-STAGE void st_quantize(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ C, WaveLds& L, int lane, int mode, int target)
+template <class LdsT> STAGE void st_quantize(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ C, LdsT& L, int lane, int mode, int target)
 {
     const int nt = PI(ylen), fs = PI(fs), tb = CI(total_bits);
     const float offs = PI(hrmode) ? 0.5f : 0.375f;
@@ -2030,7 +2035,7 @@ STAGE void st_quantize(const lc3d_plan* __restrict__ P, const lc3d_chan* __restr
 }
 
 /* ---- R/adjust_global_gain.c:13-50 (wave-uniform scalars) ---- */
-__device__ __forceinline__ void gain_adjust(const lc3d_plan* __restrict__ P, WaveLds& L, int& gg, int gg_min, float& gain, int target, int nBits, int& change)
+template <class LdsT> __device__ __forceinline__ void gain_adjust(const lc3d_plan* __restrict__ P, LdsT& L, int& gg, int gg_min, float& gain, int target, int nBits, int& change)
 {
     const int f = PI(fs_idx), off = CI(gg_off);
     float delta;
@@ -2055,7 +2060,7 @@ __device__ __forceinline__ void gain_adjust(const lc3d_plan* __restrict__ P, Wav
 /* ---- noise factor R/noise_factor.c:13-108 ----
  * Pass 1 finds the zero lines (ballots) and their count / index sum; pass 2 accumulates |x/gg| over them in index order,
  * the serial float sums fed from lane registers with readlane (no list in LDS). */
-STAGE void st_noise_factor(const lc3d_plan* __restrict__ P, WaveLds& L, int lane, int bw_bin)
+template <class LdsT> STAGE void st_noise_factor(const lc3d_plan* __restrict__ P, LdsT& L, int lane, int bw_bin)
 {
     const int dms = PI(dms);
     const int width = dms == 100 ? 8 : 4, first = dms == 100 ? 24 : dms == 50 ? 12 : 6, hw = (width - 2) / 2;
@@ -2163,7 +2168,7 @@ STAGE void st_noise_factor(const lc3d_plan* __restrict__ P, WaveLds& L, int lane
 /* ---- residual coding R/residual_coding.c:13-75 ----
  * The n-th non-zero coefficient (in bin order) owns residual bit n; a ballot prefix count gives n, so every lane decides and
  * stores its own bit.  High-resolution mode repeats the sweep with a halved offset (up to 20 times). */
-STAGE void st_residual(const lc3d_plan* __restrict__ P, WaveLds& L, int lane, int targetBits, int nBits)
+template <class LdsT> STAGE void st_residual(const lc3d_plan* __restrict__ P, LdsT& L, int lane, int targetBits, int nBits)
 {
     const int* xq = XQ(L);
     const float gain = unif(L.fsc[F_GAIN]);
@@ -2300,7 +2305,7 @@ __device__ __forceinline__ void ari_chunk(AriSt& w, unsigned* big, int lane, uns
     w.s8 = s8_end;
 }
 
-STAGE void st_bitstream(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ C, WaveLds& L, int lane)
+template <class LdsT> STAGE void st_bitstream(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ C, LdsT& L, int lane)
 {
     int* isc = L.isc;
     unsigned* rb = (unsigned*)BYTES(L);              /* backward bit string while coding; the finished frame at the end */
@@ -2779,6 +2784,7 @@ KERNEL_NAME(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans
 /* C-ABI device shim (lc3_shim.h): context, uploads, launch                                          */
 /* ------------------------------------------------------------------------------------------------ */
 #include "lc3_enc_front.inc"       /* lc3_enc_front_kernel (or _big): the stateless front, frame-parallel */
+#include "lc3_enc_seq.inc"         /* lc3_enc_pitch_kernel, lc3_enc_seq_kernel (or _big): the two sequential kernels of the pipelined path */
 #include "lc3_dec_kernels.inc"     /* lc3_dec_{plc,imdct,synth}_kernel, or the _big imdct / synth kernels in the large-layout object */
 #ifndef LC3_BIG                 /* the large-layout object holds only its kernels */
 #include "lc3_dec_parse.inc"
@@ -2788,10 +2794,14 @@ extern "C" __global__ void lc3_encode_kernel_big(const lc3d_plan* __restrict__ P
                                                  uint8_t* __restrict__ status, int dT, int dt0, const float* __restrict__ spec, const float* __restrict__ frec,
                                                  const float* __restrict__ xnext);
 extern "C" __global__ void lc3_enc_front_kernel_big(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans, const float* __restrict__ state, const void* __restrict__ pcm,
-                                                    int bitdepth, int T, int ncs, float* __restrict__ spec, float* __restrict__ rec, float* __restrict__ xnext);
+                                                    int bitdepth, int T, int tb, int nt, int ncs, float* __restrict__ spec, float* __restrict__ rec, float* __restrict__ xnext);
+extern "C" __global__ void lc3_enc_seq_kernel_big(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans, float* __restrict__ state, int T, int t0, int nt, int ncs,
+                                                  int* __restrict__ dump, int dstride, int dT, int dt0, uint8_t* __restrict__ status, const float* __restrict__ spec,
+                                                  const float* __restrict__ frec, const float* __restrict__ xnext);
 #include "lc3_enc_pack.inc"
 #include "lc3_enc_snsvq.inc"
 #include "lc3_enc_pre.inc"
+#define LC3D_MAX_RUNS 16
 struct lc3hip_ctx {
     int device, ncs, n_streams, channels, N, big, state_words;
     lc3d_plan* d_plan; lc3d_chan* d_chans; float* d_state;
@@ -2803,7 +2813,7 @@ struct lc3hip_ctx {
     /* host-pointer pipeline (lc3hip_encode_host): two chunk slots, each with device staging and (for pageable callers) pinned staging */
     void* hp_dpcm[2]; void* hp_pin_in[2]; size_t hp_pcm_cap, hp_pin_in_cap;
     hipStream_t s_h2d; hipEvent_t ev_h2d[2], ev_k[2];
-    hipStream_t s_pre; hipEvent_t ev_fork, ev_join;
+    hipStream_t s_pre, s_fr; hipEvent_t ev_fork, ev_p[LC3D_MAX_RUNS], ev_f[LC3D_MAX_RUNS];
     hipStream_t stream, last_stream; hipEvent_t ev0, ev1; float last_ms;
 };
 
@@ -2903,59 +2913,69 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
     }
     static int split_off = -1;
     if (split_off < 0) { const char* e = getenv("LC3PLUS_ENC_NO_SPLIT"); split_off = e && e[0] == '1'; }
-    const bool split = dy12 && !split_off && dT > LC3D_FUSED_MAX_T;
-    hipStream_t sp = s;                    /* where the 12.8 kHz pre-kernels go */
-    if (dy12) {
-        if (split) {
-            /* the pitch path's pre-kernels (resampler, HP50: only B / 64 waves, one long chain each) and the spectral front are independent
-             * until the sequential kernel needs both: a second stream lets the HP50 waves run beside the front kernel */
-            if (!c->s_pre) { HIPCHK(hipStreamCreateWithFlags(&c->s_pre, hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming)); }
-            HIPCHK(hipEventRecord(c->ev_fork, s)); HIPCHK(hipStreamWaitEvent(c->s_pre, c->ev_fork, 0));
-            sp = c->s_pre;
+    const bool split = dy12 && ddump && !split_off;
+    const int mc = c->big ? LC3D_MEMCAP_BIG : LC3D_MEMCAP_STD;
+    if (!split) {
+        /* everything in lc3_encode_kernel (traced, diagnostic and very short launches), behind the 12.8 kHz pre-kernels when they apply */
+        if (dy12) {
+            const unsigned runs = (unsigned)((n_frames + PRE_FPW - 1) / PRE_FPW);
+            hipLaunchKernelGGL(lc3_enc_resample_kernel, dim3((unsigned)c->ncs * runs), dim3(WAVE), 0, s, c->d_plan, c->d_state, c->state_words, mc, dpcm, bitdepth, n_frames, 0, n_frames, c->ncs, dy12);
+            hipLaunchKernelGGL(lc3_enc_hp50_kernel, dim3((unsigned)((c->ncs + WAVE - 1) / WAVE)), dim3(WAVE), 0, s, c->d_plan, c->d_state, c->state_words, LC3D_ST_SCAL(mc), n_frames, 0, n_frames, c->ncs, dy12);
+            HIPCHK(hipGetLastError());
         }
-        const int mc = c->big ? LC3D_MEMCAP_BIG : LC3D_MEMCAP_STD;
-        const unsigned runs = (unsigned)((n_frames + PRE_FPW - 1) / PRE_FPW);
-        hipLaunchKernelGGL(lc3_enc_resample_kernel, dim3((unsigned)c->ncs * runs), dim3(WAVE), 0, sp, c->d_plan, c->d_state, c->state_words, mc, dpcm, bitdepth, n_frames, c->ncs, dy12);
-        hipLaunchKernelGGL(lc3_enc_hp50_kernel, dim3((unsigned)((c->ncs + WAVE - 1) / WAVE)), dim3(WAVE), 0, sp, c->d_plan, c->d_state, c->state_words, LC3D_ST_SCAL(mc), n_frames, c->ncs, dy12);
-        HIPCHK(hipGetLastError());
-        if (split) HIPCHK(hipEventRecord(c->ev_join, sp));
-    }
-    /* the stateless front (MDCT ... scale factors) for all frames at once, the attack detector's decision one stream per lane, the SNS
-     * quantiser one frame per lane, then the sequential kernel; traced, diagnostic and very short launches keep everything in the
-     * sequential kernel */
-    float* dspec = nullptr; float* dfrec = nullptr;
-    { if (split) {
-        const int mc = c->big ? LC3D_MEMCAP_BIG : LC3D_MEMCAP_STD;
+        if (c->big) hipLaunchKernelGGL(lc3_encode_kernel_big, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames,
+                                       dout, out_stride, c->ncs, dtr, ddump, dstride, dy12, c->d_status, dT, dt0, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr);
+        else hipLaunchKernelGGL(lc3_encode_kernel, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames,
+                                dout, out_stride, c->ncs, dtr, ddump, dstride, dy12, c->d_status, dT, dt0, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr);
+    } else {
+        /* The pipelined path.  Per run of frames: on one side stream the pitch chain (resampler per frame, HP50 one stream per lane, OLPA +
+         * LTPF one stream per wave), on another the frame-parallel front (MDCT ... scale factors), the attack decision and the SNS
+         * quantiser (one frame per lane); on the launch stream the rate chain (lc3_enc_seq_kernel), which waits for both.  The side kernels
+         * of run k+1 are resident beside the rate kernel of run k (they were sized for that: lc3_enc_seq.inc). */
         const size_t ns = (size_t)c->ncs * n_frames * c->N, nr = (size_t)c->ncs * n_frames * FR_WORDS;
         if (c->spec_cap < ns) { if (c->d_spec) HIPCHK(hipFree(c->d_spec)); c->d_spec = nullptr; c->spec_cap = 0; HIPCHK(hipMalloc((void**)&c->d_spec, ns * sizeof(float))); c->spec_cap = ns; }
         if (c->frec_cap < nr) { if (c->d_frec) HIPCHK(hipFree(c->d_frec)); c->d_frec = nullptr; c->frec_cap = 0; HIPCHK(hipMalloc((void**)&c->d_frec, nr * sizeof(float))); c->frec_cap = nr; }
         if (!c->d_xnext) HIPCHK(hipMalloc((void**)&c->d_xnext, (size_t)c->ncs * mc * sizeof(float)));
-        dspec = c->d_spec; dfrec = c->d_frec;
-        const unsigned runs = (unsigned)((n_frames + FRONT_FPW - 1) / FRONT_FPW);
-        if (c->big) hipLaunchKernelGGL(lc3_enc_front_kernel_big, dim3((unsigned)c->ncs * runs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames, c->ncs, dspec, dfrec, c->d_xnext);
-        else hipLaunchKernelGGL(lc3_enc_front_kernel, dim3((unsigned)c->ncs * runs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames, c->ncs, dspec, dfrec, c->d_xnext);
-        HIPCHK(hipGetLastError());
-        const long long nfr = (long long)c->ncs * n_frames;
-        if (c->any_attack) {
-            const int mcs = c->big ? LC3D_MEMCAP_BIG : LC3D_MEMCAP_STD;
-            hipLaunchKernelGGL(lc3_enc_attack_kernel, dim3((unsigned)((c->ncs + WAVE - 1) / WAVE)), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, c->state_words, LC3D_ST_SCAL(mcs), dfrec, n_frames, c->ncs);
+        if (!c->s_pre) {
+            HIPCHK(hipStreamCreateWithFlags(&c->s_pre, hipStreamNonBlocking)); HIPCHK(hipStreamCreateWithFlags(&c->s_fr, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+            for (int i = 0; i < LC3D_MAX_RUNS; i++) { HIPCHK(hipEventCreateWithFlags(&c->ev_p[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_f[i], hipEventDisableTiming)); }
+        }
+        float* dspec = c->d_spec; float* dfrec = c->d_frec;
+        int R = n_frames >= 8 * 8 ? 8 : n_frames / 8;
+        if (R < 1) R = 1;
+        { const char* e = getenv("LC3PLUS_ENC_RUNS"); if (e && atoi(e) >= 1 && atoi(e) <= LC3D_MAX_RUNS) R = atoi(e); }     /* diagnostic */
+        const int Tr = (n_frames + R - 1) / R;
+        HIPCHK(hipEventRecord(c->ev_fork, s)); HIPCHK(hipStreamWaitEvent(c->s_pre, c->ev_fork, 0)); HIPCHK(hipStreamWaitEvent(c->s_fr, c->ev_fork, 0));
+        for (int k = 0, tb = 0; tb < n_frames; k++, tb += Tr) {
+            const int nt = n_frames - tb < Tr ? n_frames - tb : Tr;
+            const unsigned pruns = (unsigned)((nt + PRE_FPW - 1) / PRE_FPW), fruns = (unsigned)((nt + FRONT_FPW - 1) / FRONT_FPW);
+            hipLaunchKernelGGL(lc3_enc_resample_kernel, dim3((unsigned)c->ncs * pruns), dim3(WAVE), 0, c->s_pre, c->d_plan, c->d_state, c->state_words, mc, dpcm, bitdepth, n_frames, tb, nt, c->ncs, dy12);
+            hipLaunchKernelGGL(lc3_enc_hp50_kernel, dim3((unsigned)((c->ncs + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->s_pre, c->d_plan, c->d_state, c->state_words, LC3D_ST_SCAL(mc), n_frames, tb, nt, c->ncs, dy12);
+            hipLaunchKernelGGL(lc3_enc_pitch_kernel, dim3(c->ncs), dim3(WAVE), 0, c->s_pre, c->d_plan, c->d_chans, c->d_state, c->state_words, mc, dy12, n_frames, tb, nt, c->ncs, dfrec);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(c->ev_p[k], c->s_pre));
+            if (c->big) hipLaunchKernelGGL(lc3_enc_front_kernel_big, dim3((unsigned)c->ncs * fruns), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames, tb, nt, c->ncs, dspec, dfrec, c->d_xnext);
+            else hipLaunchKernelGGL(lc3_enc_front_kernel, dim3((unsigned)c->ncs * fruns), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames, tb, nt, c->ncs, dspec, dfrec, c->d_xnext);
+            if (c->any_attack)
+                hipLaunchKernelGGL(lc3_enc_attack_kernel, dim3((unsigned)((c->ncs + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, c->state_words, LC3D_ST_SCAL(mc), dfrec, n_frames, tb, nt, c->ncs);
+            const long long nfr = (long long)c->ncs * nt;
+            hipLaunchKernelGGL(lc3_enc_snsvq_kernel, dim3((unsigned)((nfr + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->s_fr, c->d_plan, dfrec, n_frames, tb, nt, c->ncs, c->any_attack);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(c->ev_f[k], c->s_fr));
+            HIPCHK(hipStreamWaitEvent(s, c->ev_p[k], 0)); HIPCHK(hipStreamWaitEvent(s, c->ev_f[k], 0));
+            if (c->big) hipLaunchKernelGGL(lc3_enc_seq_kernel_big, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, n_frames, tb, nt, c->ncs, ddump, dstride, dT, dt0, c->d_status, dspec, dfrec, c->d_xnext);
+            else hipLaunchKernelGGL(lc3_enc_seq_kernel, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, n_frames, tb, nt, c->ncs, ddump, dstride, dT, dt0, c->d_status, dspec, dfrec, c->d_xnext);
             HIPCHK(hipGetLastError());
         }
-        hipLaunchKernelGGL(lc3_enc_snsvq_kernel, dim3((unsigned)((nfr + WAVE - 1) / WAVE)), dim3(WAVE), 0, s, c->d_plan, dfrec, nfr, c->any_attack);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamWaitEvent(s, c->ev_join, 0));
-      } }
-    if (c->big) hipLaunchKernelGGL(lc3_encode_kernel_big, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames,
-                                   dout, out_stride, c->ncs, dtr, ddump, dstride, dy12, c->d_status, dT, dt0, dspec, dfrec, c->d_xnext);
-    else hipLaunchKernelGGL(lc3_encode_kernel, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames,
-                            dout, out_stride, c->ncs, dtr, ddump, dstride, dy12, c->d_status, dT, dt0, dspec, dfrec, c->d_xnext);
+    }
     if (ddump && pack) {
         HIPCHK(hipGetLastError());
         const int wpg = 4;
         const size_t per_wave = (size_t)PK_XBUF * WAVE * sizeof(unsigned);
         const long long tasks = (long long)c->ncs * dT, per_wg = (long long)wpg * WAVE;
         hipLaunchKernelGGL(lc3_enc_pack_kernel, dim3((unsigned)((tasks + per_wg - 1) / per_wg)), dim3(wpg * WAVE), per_wave * wpg, s, c->d_plan, c->d_chans, ddump, dstride,
-                           dT, c->ncs, dout, out_stride, c->d_status);
+                           dT, 0, dT, c->ncs, dout, out_stride, c->d_status);
     }
     HIPCHK(hipGetLastError());
     c->last_stream = s;
@@ -3108,7 +3128,7 @@ extern "C" int lc3hip_destroy(void* ctx)
         if (c->ev_k[i]) hipEventDestroy(c->ev_k[i]);
     }
     if (c->s_h2d) hipStreamDestroy(c->s_h2d);
-    if (c->s_pre) { hipStreamDestroy(c->s_pre); hipEventDestroy(c->ev_fork); hipEventDestroy(c->ev_join); }
+    if (c->s_pre) { hipStreamDestroy(c->s_pre); hipStreamDestroy(c->s_fr); hipEventDestroy(c->ev_fork); for (int i = 0; i < LC3D_MAX_RUNS; i++) { hipEventDestroy(c->ev_p[i]); hipEventDestroy(c->ev_f[i]); } }
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); }

@@ -78,7 +78,8 @@ typedef struct {
 #define FR_ATT   40                      /* attack detector (R/attack_detector.c): 4 block energies, [44..45] the filter memory after this frame, [46] the flag (lc3_enc_attack_kernel) */
 #define FR_ATTM  44
 #define FR_ATTFLAG 46
-#define FR_WORDS 48
+#define FR_LTPF  48                      /* 4 ints from lc3_enc_pitch_kernel: LTPF flag, active, pitch index, side bits (R/ltpf_coder.c:245-254) */
+#define FR_WORDS 52
 
 /* per channel-frame status bits of the encoder: conditions the reference only asserts on (SURVEY 5 "failure detection") */
 #define LC3D_ENC_ST_BIT_BUDGET  1        /* side information + range-coder bits exceed the frame (R/ari_codec.c:777) */
