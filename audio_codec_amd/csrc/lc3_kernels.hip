@@ -2802,6 +2802,7 @@ extern "C" __global__ void lc3_enc_seq_kernel_big(const lc3d_plan* __restrict__ 
 #include "lc3_enc_snsvq.inc"
 #include "lc3_enc_pre.inc"
 #define LC3D_MAX_RUNS 16
+#define LC3D_RUN_FRAMES 4
 struct lc3hip_ctx {
     int device, ncs, n_streams, channels, N, big, state_words;
     lc3d_plan* d_plan; lc3d_chan* d_chans; float* d_state;
@@ -2942,7 +2943,8 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
             for (int i = 0; i < LC3D_MAX_RUNS; i++) { HIPCHK(hipEventCreateWithFlags(&c->ev_p[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_f[i], hipEventDisableTiming)); }
         }
         float* dspec = c->d_spec; float* dfrec = c->d_frec;
-        int R = n_frames >= 8 * 8 ? 8 : n_frames / 8;
+        int R = (n_frames + LC3D_RUN_FRAMES - 1) / LC3D_RUN_FRAMES;              /* runs of LC3D_RUN_FRAMES frames */
+        if (R > LC3D_MAX_RUNS) R = LC3D_MAX_RUNS;
         if (R < 1) R = 1;
         { const char* e = getenv("LC3PLUS_ENC_RUNS"); if (e && atoi(e) >= 1 && atoi(e) <= LC3D_MAX_RUNS) R = atoi(e); }     /* diagnostic */
         const int Tr = (n_frames + R - 1) / R;
@@ -3128,7 +3130,8 @@ extern "C" int lc3hip_destroy(void* ctx)
         if (c->ev_k[i]) hipEventDestroy(c->ev_k[i]);
     }
     if (c->s_h2d) hipStreamDestroy(c->s_h2d);
-    if (c->s_pre) { hipStreamDestroy(c->s_pre); hipStreamDestroy(c->s_fr); hipEventDestroy(c->ev_fork); for (int i = 0; i < LC3D_MAX_RUNS; i++) { hipEventDestroy(c->ev_p[i]); hipEventDestroy(c->ev_f[i]); } }
+    if (c->s_pre) { hipStreamDestroy(c->s_pre); hipStreamDestroy(c->s_fr); hipEventDestroy(c->ev_fork);
+                    for (int i = 0; i < LC3D_MAX_RUNS; i++) { hipEventDestroy(c->ev_p[i]); hipEventDestroy(c->ev_f[i]); } }
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); }
