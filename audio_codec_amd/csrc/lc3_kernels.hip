@@ -2794,7 +2794,7 @@ extern "C" __global__ void lc3_encode_kernel_big(const lc3d_plan* __restrict__ P
                                                  uint8_t* __restrict__ status, int dT, int dt0, const float* __restrict__ spec, const float* __restrict__ frec,
                                                  const float* __restrict__ xnext);
 extern "C" __global__ void lc3_enc_front_kernel_big(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans, const float* __restrict__ state, const void* __restrict__ pcm,
-                                                    int bitdepth, int T, int tb, int nt, int ncs, float* __restrict__ spec, float* __restrict__ rec, float* __restrict__ xnext);
+                                                    int bitdepth, int T, int tb, int nt, int fpw, int ncs, float* __restrict__ spec, float* __restrict__ rec, float* __restrict__ xnext);
 extern "C" __global__ void lc3_enc_seq_kernel_big(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans, float* __restrict__ state, int T, int t0, int nt, int ncs,
                                                   int* __restrict__ dump, int dstride, int dT, int dt0, uint8_t* __restrict__ status, const float* __restrict__ spec,
                                                   const float* __restrict__ frec, const float* __restrict__ xnext);
@@ -2948,17 +2948,30 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
         if (R < 1) R = 1;
         { const char* e = getenv("LC3PLUS_ENC_RUNS"); if (e && atoi(e) >= 1 && atoi(e) <= LC3D_MAX_RUNS) R = atoi(e); }     /* diagnostic */
         const int Tr = (n_frames + R - 1) / R;
-        HIPCHK(hipEventRecord(c->ev_fork, s)); HIPCHK(hipStreamWaitEvent(c->s_pre, c->ev_fork, 0)); HIPCHK(hipStreamWaitEvent(c->s_fr, c->ev_fork, 0));
-        for (int k = 0, tb = 0; tb < n_frames; k++, tb += Tr) {
+        HIPCHK(hipEventRecord(c->ev_fork, s));
+        HIPCHK(hipStreamWaitEvent(c->s_pre, c->ev_fork, 0)); HIPCHK(hipStreamWaitEvent(c->s_fr, c->ev_fork, 0));
+        /* The 12.8 kHz pre-kernels run ahead in larger pieces than the runs: the HP50 kernel (one stream per lane, B / 64 waves) costs ~0.1 ms
+         * per launch whatever the frame count, which per run would make its stream the slowest.  First piece = the first run (the rate
+         * kernel should start early), then four runs at a time, in stream order between the pitch kernels that need them.  (More side
+         * streams than these two do not help: HIP multiplexes streams onto a few hardware queues and kernels of two streams that share
+         * one run back to back.) */
+        for (int k = 0, tb = 0, hb = 0, hk = 0; tb < n_frames; k++, tb += Tr) {
             const int nt = n_frames - tb < Tr ? n_frames - tb : Tr;
-            const unsigned pruns = (unsigned)((nt + PRE_FPW - 1) / PRE_FPW), fruns = (unsigned)((nt + FRONT_FPW - 1) / FRONT_FPW);
-            hipLaunchKernelGGL(lc3_enc_resample_kernel, dim3((unsigned)c->ncs * pruns), dim3(WAVE), 0, c->s_pre, c->d_plan, c->d_state, c->state_words, mc, dpcm, bitdepth, n_frames, tb, nt, c->ncs, dy12);
-            hipLaunchKernelGGL(lc3_enc_hp50_kernel, dim3((unsigned)((c->ncs + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->s_pre, c->d_plan, c->d_state, c->state_words, LC3D_ST_SCAL(mc), n_frames, tb, nt, c->ncs, dy12);
+            if (tb >= hb) {
+                const int hn0 = hk == 0 ? Tr : 4 * Tr, hn = n_frames - hb < hn0 ? n_frames - hb : hn0;
+                const unsigned pruns = (unsigned)((hn + PRE_FPW - 1) / PRE_FPW);
+                hipLaunchKernelGGL(lc3_enc_resample_kernel, dim3((unsigned)c->ncs * pruns), dim3(WAVE), 0, c->s_pre, c->d_plan, c->d_state, c->state_words, mc, dpcm, bitdepth, n_frames, hb, hn, c->ncs, dy12);
+                hipLaunchKernelGGL(lc3_enc_hp50_kernel, dim3((unsigned)((c->ncs + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->s_pre, c->d_plan, c->d_state, c->state_words, LC3D_ST_SCAL(mc), n_frames, hb, hn, c->ncs, dy12);
+                HIPCHK(hipGetLastError());
+                hb += hn; hk++;
+            }
             hipLaunchKernelGGL(lc3_enc_pitch_kernel, dim3(c->ncs), dim3(WAVE), 0, c->s_pre, c->d_plan, c->d_chans, c->d_state, c->state_words, mc, dy12, n_frames, tb, nt, c->ncs, dfrec);
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(c->ev_p[k], c->s_pre));
-            if (c->big) hipLaunchKernelGGL(lc3_enc_front_kernel_big, dim3((unsigned)c->ncs * fruns), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames, tb, nt, c->ncs, dspec, dfrec, c->d_xnext);
-            else hipLaunchKernelGGL(lc3_enc_front_kernel, dim3((unsigned)c->ncs * fruns), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames, tb, nt, c->ncs, dspec, dfrec, c->d_xnext);
+            const int fpw = nt < FRONT_FPW ? nt : FRONT_FPW;
+            const unsigned fruns = (unsigned)((nt + fpw - 1) / fpw);
+            if (c->big) hipLaunchKernelGGL(lc3_enc_front_kernel_big, dim3((unsigned)c->ncs * fruns), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames, tb, nt, fpw, c->ncs, dspec, dfrec, c->d_xnext);
+            else hipLaunchKernelGGL(lc3_enc_front_kernel, dim3((unsigned)c->ncs * fruns), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames, tb, nt, fpw, c->ncs, dspec, dfrec, c->d_xnext);
             if (c->any_attack)
                 hipLaunchKernelGGL(lc3_enc_attack_kernel, dim3((unsigned)((c->ncs + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, c->state_words, LC3D_ST_SCAL(mc), dfrec, n_frames, tb, nt, c->ncs);
             const long long nfr = (long long)c->ncs * nt;
