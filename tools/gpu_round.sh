@@ -36,16 +36,21 @@ for w in "$WL".split():
         with open("profiles/%s_%s_kernel_stats.csv" % (tag, w), "w") as o:
             o.write("Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs\n")
             for r in rows: o.write("%s,%s,%s,%s,%s,%s,%s\n" % (r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]))
-# ---- PMC ----
+# ---- PMC ----  a call is several launches of most kernels (runs of frames): per-call value = sum over the launches of a pass / calls in
+# that pass, a call being one launch of the kernel that runs once per call (lc3_enc_pack_kernel / lc3_dec_synth_kernel)
 summ = {}
 for w in ("c1", "d1"):
     acc = collections.defaultdict(list)
     for f in glob.glob("%s/pmc_%s_*/**/*counter_collection.csv" % (out, w), recursive=True):
+        per = collections.defaultdict(float); calls = collections.Counter()
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0]
-            if k.startswith("lc3_dec" if w[0] == "d" else "lc3_enc"): acc[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
+            if k.startswith("lc3_dec" if w[0] == "d" else "lc3_enc"):
+                per[(k, r["Counter_Name"])] += float(r["Counter_Value"])
+                if k in ("lc3_enc_pack_kernel", "lc3_dec_synth_kernel"): calls[r["Counter_Name"]] += 1
+        for (k, cn), v in per.items(): acc[(k, cn)].append(v / max(1, calls[cn]))
     with open("profiles/%s_%s_pmc.txt" % (tag, w), "w") as o:
-        for k in sorted(acc): o.write("%s %s %.0f (mean of %d launches)\n" % (k[0], k[1], sum(acc[k]) / len(acc[k]), len(acc[k])))
+        for k in sorted(acc): o.write("%s %s %.0f (per call, all launches of the call summed)\n" % (k[0], k[1], sum(acc[k]) / len(acc[k])))
     summ[w] = {k: sum(v) / len(v) for k, v in acc.items()}
 def tot(w, c): return sum(v for (k, cn), v in summ[w].items() if cn == c)
 ents = []
