@@ -238,6 +238,13 @@ static void build_plan(const geom_t* g, lc3d_plan* p)
         float f = (float)t7; if ((double)f < t7) f = nextafterf(f, INFINITY); p->c_thr7_up = f;
         f = (float)t50; if ((double)f > t50) f = nextafterf(f, -INFINITY); p->c_thr50_dn = f;
     }
+    for (int t = 0; t < 1024; t++) {
+        unsigned w = 0, e[4];
+        for (int j = 0; j < 4; j++) { const unsigned pk = lc3t_ac_ctx_lut[t + 1024 * j]; w |= pk << (8 * j); e[j] = lc3t_ac_bits[pk * 17 + 16]; }
+        p->q_lut4[t] = w;
+        p->q_esc[t][0] = (uint16_t)e[0]; p->q_esc[t][1] = (uint16_t)(e[0] + e[1]); p->q_esc[t][2] = (uint16_t)(e[0] + e[1] + e[2]); p->q_esc[t][3] = (uint16_t)e[3];
+    }
+    memcpy(p->q_bits, lc3t_ac_bits, sizeof p->q_bits);
     memset(p->band_of_bin, 255, sizeof p->band_of_bin);
     const uint16_t* be = &lc3t_band_pool[g->tab->band_off];
     for (int b = 0; b < g->nbands; b++) for (int j = be[b]; j < be[b + 1] && j < LC3D_MAX_N; j++) p->band_of_bin[j] = (uint8_t)b;

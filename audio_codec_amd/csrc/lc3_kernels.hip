@@ -73,6 +73,7 @@
 /* LDS slice of one wave (~12.8 KB -> 12 waves per CU)                                                */
 /* ------------------------------------------------------------------------------------------------ */
 struct __attribute__((aligned(16))) WaveLds {
+    static constexpr bool CDW = true;       /* st_quantize leaves the per-tuple coder words st_bitstream reads */
     static constexpr int MISC = 368;   /* = SM_MISC: where the scratch vectors of this layout's sm[] start */
     static constexpr int XOFF = MEMCAP; /* the frame half of xbuf (XCUR / XQ) */
     float xbuf[MEMCAP + MAXN];  /* [MDCT/resampler memory right-aligned in 0..MEMCAP | current frame X]; once the MDCT fold has consumed the
@@ -1963,67 +1964,75 @@ template <class LdsT> STAGE void st_quantize(const lc3d_plan* __restrict__ P, co
     int lastnz2 = mode < 0 ? lastnz + 1 : 2;
     int nbits2 = 0, base = 0, nlsb = 0, ct1 = 0, ct2 = 0;
     SUB(28);
-    /* Two dependent rounds of table reads per pass (context LUT -> bit costs).  Pass p+1's quantised values, contexts and LUT
-     * reads are formed while pass p's bit costs are still in flight. */
-    int x0N = 0, x1N = 0, nshN = 0, lev1N = 0, maxlevN = 0, symN = 0, tinN = 0, clsN = 0, needN = -1, pk0N = 0, pk1N = 0, pk2N = 0, pk3N = 0;
-#define QPASS_HEAD(c0_) do { const int p_ = (c0_) + lane; const bool act_ = p_ < ntup; \
-        x0N = act_ ? xq[2 * p_] : 0; x1N = act_ ? xq[2 * p_ + 1] : 0; \
-        const int a_ = x0N < 0 ? -x0N : x0N, b_ = x1N < 0 ? -x1N : x1N, mx_ = imax(a_, b_); \
-        nshN = mx_ >= 4 ? ilog2((unsigned)mx_) - 1 : 0; \
-        const int af_ = a_ >> nshN, bf_ = b_ >> nshN; \
-        lev1N = imin(nshN, 3); const int levm_ = lev1N - 1; \
-        const int tval_ = levm_ <= 0 ? 1 + (af_ + bf_) * (levm_ + 2) : 13 + levm_; \
-        /* context = the two previous tuples' values: wave_shr:1 hands lane 0 the carry-in of the previous pass */ \
-        const int t1_ = dpp_i<DPP_WSHR1>(ct1, tval_), t2_ = dpp_i<DPP_WSHR1>(ct2, t1_); \
-        tinN = 16 * (t2_ & 15) + t1_ + rate; if (2 * p_ > nt / 2) tinN += 256; \
-        maxlevN = mx_ == 0 ? -1 : flog2f_int((unsigned)imax(mx_, 3)) - 1; \
-        symN = af_ + 4 * bf_; \
-        clsN = imin(imax(maxlevN, 0), 3);             /* class of the final symbol in the coder (R/ari_codec.c:723-727) */ \
-        needN = act_ ? imax(lev1N, clsN) : -1; \
-        if (needN >= 0) pk0N = lc3t_ac_ctx_lut[tinN]; \
-        if (__ballot(needN >= 1)) { if (needN >= 1) pk1N = lc3t_ac_ctx_lut[tinN + 1024]; \
-            if (__ballot(needN >= 2)) { if (needN >= 2) pk2N = lc3t_ac_ctx_lut[tinN + 2048]; if (needN >= 3) pk3N = lc3t_ac_ctx_lut[tinN + 3072]; } } \
-        ct2 = __builtin_amdgcn_readlane(tval_, 62); ct1 = __builtin_amdgcn_readlane(tval_, 63); } while (0)
-    if (ntup > 0) QPASS_HEAD(0);
-    for (int c0 = 0; c0 < ntup; c0 += WAVE) {
-        const int p = c0 + lane; const bool act = p < ntup;
-        const int x0 = x0N, x1 = x1N, nsh = nshN, lev1 = lev1N, maxlev = maxlevN, sym = symN, tin = tinN, cls_f = clsN, need = needN;
-        const int pk0 = pk0N, pk1 = pk1N, pk2c = pk2N, pk3 = pk3N;
-        const int a0 = x0 < 0 ? -x0 : x0, b0 = x1 < 0 ? -x1 : x1;
-        /* bit costs (1/2048 bit) of the escape symbols of classes 0..3 (levels >= 3 share class 3) and of the final symbol */
-        int e0 = 0, e1 = 0, e2 = 0, e3 = 0;
-        if (__ballot(need >= 1)) {
-            if (nsh >= 1 && act) e0 = lc3t_ac_bits[pk0 * 17 + 16];
-            if (__ballot(need >= 2)) {
-                if (nsh >= 2 && act) e1 = lc3t_ac_bits[pk1 * 17 + 16];
-                if (nsh >= 3 && act) e2 = lc3t_ac_bits[pk2c * 17 + 16];
-                if (nsh >= 4 && act) e3 = lc3t_ac_bits[pk3 * 17 + 16];
-            }
+    /* Exact bit count of the 2-tuples in coding order.  Three phases over the (at most NP) groups of 64 tuples, so that the two dependent
+     * rounds of table reads are paid once per call and not once per group:
+     *   A  per tuple: escape count, final symbol, context (the two previous tuples' values: wave_shr:1, lanes 62 / 63 carry into the next
+     *      group); reads of the context's model indices (one word for the four escape classes) and escape costs (plan tables q_lut4, q_esc);
+     *   B  read of the final symbol's cost under the model of its class;
+     *   C  bits of the tuple, running sum, truncation point (R/quantize_spec.c:150-166). */
+    constexpr int NP = (MAXN / 2 + WAVE - 1) / WAVE;
+    int meta[NP], mlev[NP]; unsigned lutw[NP]; uint2 escw[NP]; int bsym[NP];
+    const uint32_t* __restrict__ qlut = P->q_lut4; const uint2* __restrict__ qesc = (const uint2*)P->q_esc; const uint16_t* __restrict__ qbits = P->q_bits;
+    const int half = nt / 2;
+#pragma unroll
+    for (int k = 0; k < NP; k++) {
+        meta[k] = 0; mlev[k] = 0; lutw[k] = 0; escw[k] = make_uint2(0, 0);
+        if (64 * k < ntup) {
+            const int p_ = 64 * k + lane; const bool act_ = p_ < ntup;
+            const int pc_ = imin(p_, MAXN / 2 - 1);
+            const int x0 = act_ ? xq[2 * pc_] : 0, x1 = act_ ? xq[2 * pc_ + 1] : 0;
+            const int a_ = x0 < 0 ? -x0 : x0, b_ = x1 < 0 ? -x1 : x1, mx_ = imax(a_, b_);
+            const int nsh = mx_ >= 4 ? ilog2((unsigned)mx_) - 1 : 0;
+            const int af_ = a_ >> nsh, bf_ = b_ >> nsh;
+            const int lev1 = imin(nsh, 3), s_ = af_ + bf_;
+            const int tval_ = lev1 <= 1 ? 1 + (s_ << lev1) : 12 + lev1;
+            const int t1_ = dpp_i<DPP_WSHR1>(ct1, tval_), t2_ = dpp_i<DPP_WSHR1>(ct2, t1_);
+            ct2 = __builtin_amdgcn_readlane(tval_, 62); ct1 = __builtin_amdgcn_readlane(tval_, 63);
+            int tin = 16 * (t2_ & 15) + t1_ + rate; if (2 * p_ > half) tin += 256;
+            if (!act_) tin = 0;
+            lutw[k] = qlut[tin]; escw[k] = qesc[tin];
+            const int sh1 = nsh > 0 ? 1 : 0, am_ = a_ >> sh1, bm_ = b_ >> sh1;
+            /* nsh | lev1 << 5 | sym << 7 | non-zero values << 11 | non-zero values without their first LSB << 13 | values that are only that LSB << 15 | act << 17 | tin << 18 */
+            meta[k] = nsh | (lev1 << 5) | ((af_ + 4 * bf_) << 7) | ((imin(a_, 1) + imin(b_, 1)) << 11) | ((imin(am_, 1) + imin(bm_, 1)) << 13)
+                      | (((am_ == 0 && a_ != 0) + (bm_ == 0 && b_ != 0)) << 15) | ((act_ ? 1 : 0) << 17) | (tin << 18);
+            if constexpr (LdsT::CDW) mlev[k] = mx_ == 0 ? 0 : flog2f_int((unsigned)imax(mx_, 3));     /* max level + 1 */
         }
-        const int pkf = lev1 == 0 ? pk0 : lev1 == 1 ? pk1 : lev1 == 2 ? pk2c : pk3;
-        const int bsym = act ? lc3t_ac_bits[pkf * 17 + sym] : 0;
-        if (c0 + WAVE < ntup) QPASS_HEAD(c0 + WAVE);
-        int bits = 0, lsbc = 0;
-        if (act) {
-            if (mode <= 0) bits += (imin(a0, 1) + imin(b0, 1)) * 2048;
-            bits += e0 + e1 + e2 + e3 * (nsh - 3);
-            if (mode > 0) { if (nsh > 0) { lsbc += 2; bits += 2 * 2048 * (nsh - 1); } } else bits += 2 * 2048 * nsh;
-            bits += bsym;
-            if (mode > 0) {
-                int am = a0, bm = b0;
-                if (lev1 > 0) { am >>= 1; bm >>= 1; if (am == 0 && x0 != 0) lsbc++; if (bm == 0 && x1 != 0) lsbc++; }
-                bits += (imin(am, 1) + imin(bm, 1)) * 2048;
-            }
-            const int pkc = cls_f == 0 ? pk0 : cls_f == 1 ? pk1 : cls_f == 2 ? pk2c : pk3;
-            cdw[p] = (uint32_t)tin | ((uint32_t)(maxlev + 1) << 10) | ((uint32_t)pkc << 16) | ((uint32_t)sym << 22);
-        }
-        const int incl = wave_incl_scan_i(bits, lane) + base;
-        const unsigned long long ok = __ballot(act && mode >= 0 && (a0 != 0 || b0 != 0) && incl <= target * 2048);
-        if (ok) { const int hl = 63 - __clzll((long long)ok); lastnz2 = 2 * (c0 + hl) + 2; nbits2 = __builtin_amdgcn_readlane(incl, hl); }
-        base = __builtin_amdgcn_readlane(incl, 63);
-        if (mode > 0) nlsb += wave_sum_i(lsbc);
     }
-#undef QPASS_HEAD
+#pragma unroll
+    for (int k = 0; k < NP; k++) {
+        bsym[k] = 0;
+        if (64 * k < ntup) {
+            const int lev1 = (meta[k] >> 5) & 3, sym = (meta[k] >> 7) & 15;
+            const int pkf = (int)((lutw[k] >> (8 * lev1)) & 255u);
+            bsym[k] = qbits[pkf * 17 + sym];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NP; k++) {
+        if (64 * k < ntup) {
+            const int m_ = meta[k], nsh = m_ & 31, act = (m_ >> 17) & 1;
+            const unsigned w_ = nsh >= 3 ? escw[k].y : escw[k].x;
+            const int cv = (int)(nsh == 2 ? w_ >> 16 : w_ & 0xffffu), e3 = (int)(escw[k].y >> 16);
+            int bits = nsh == 0 ? 0 : cv + e3 * imax(nsh - 3, 0);
+            int lsbc = 0;
+            if (mode <= 0) bits += ((m_ >> 11) & 3) * 2048 + 4096 * nsh;
+            else { bits += ((m_ >> 13) & 3) * 2048 + (nsh > 0 ? 4096 * (nsh - 1) : 0); lsbc = (nsh > 0 ? 2 : 0) + ((m_ >> 15) & 3); }
+            bits += bsym[k];
+            if (!act) { bits = 0; lsbc = 0; }
+            if constexpr (LdsT::CDW) {
+                if (act) {
+                    const int cls_f = imin(imax(mlev[k] - 1, 0), 3);          /* class of the final symbol in the coder (R/ari_codec.c:723-727) */
+                    const unsigned pkc = (lutw[k] >> (8 * cls_f)) & 255u;
+                    cdw[64 * k + lane] = (uint32_t)(m_ >> 18) | ((uint32_t)mlev[k] << 10) | (pkc << 16) | ((uint32_t)((m_ >> 7) & 15) << 22);
+                }
+            }
+            const int incl = wave_incl_scan_i(bits, lane) + base;
+            const unsigned long long ok = __ballot(act && mode >= 0 && ((m_ >> 11) & 3) != 0 && incl <= target * 2048);
+            if (ok) { const int hl = 63 - __clzll((long long)ok); lastnz2 = 2 * (64 * k + hl) + 2; nbits2 = __builtin_amdgcn_readlane(incl, hl); }
+            base = __builtin_amdgcn_readlane(incl, 63);
+            if (mode > 0) nlsb += wave_sum_i(lsbc);
+        }
+    }
     SUB(29);
     int nbits = (base + 2047) >> 11;
     if (mode >= 0) nbits2 = (nbits2 + 2047) >> 11; else nbits2 = nbits;

@@ -40,6 +40,12 @@ typedef struct {
     float   gain_adj[LC3D_GAIN_TAB];               /* powf(10, (float)k/28) (float division) */
     float   rs_taps[240];                          /* 12.8 kHz resampler low-pass, phase-major: [start][m] = lp[239 - start - m*stride] (R/resamp12k8.c:48-57) */
     double  idct_cos[256];
+    /* quantiser bit estimate (R/quantize_spec.c:60-170), derived from the arithmetic-coder tables so that a 2-tuple costs three loads:
+     * per context t in [0, 1024): the probability-model index of each of the four escape classes in one word; the cost of the
+     * escape symbols as cumulative sums over the classes; and the bit-cost table itself behind the same base pointer */
+    uint16_t q_esc[1024][4];    /* e0, e0 + e1, e0 + e1 + e2, e3   with e_j = ac_bits[ctx_lut[t + 1024 j] * 17 + 16] (3 x 20480 < 2^16) */
+    uint32_t q_lut4[1024];      /* ctx_lut[t] | ctx_lut[t + 1024] << 8 | ctx_lut[t + 2048] << 16 | ctx_lut[t + 3072] << 24 */
+    uint16_t q_bits[1088];      /* = lc3t_ac_bits */
     uint8_t band_of_bin[LC3D_MAX_N];
     uint8_t pfa_src[3 * LC3D_PFA_STRIDE];   /* prime-factor DFT: gather maps of up to three stages; for N/2 = 60: [0..59] = (45k+16l)%60 */
     uint8_t pfa_dst[LC3D_PFA_STRIDE];       /* scatter of the last stage; for N/2 = 60: (15k+4l)%60 */
