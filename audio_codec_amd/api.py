@@ -18,7 +18,7 @@ EXPORTS = [
     "lc3_enc_fl", "lc3_enc16", "lc3_enc24", "lc3_enc32", "lc3_enc_free_memory", "lc3_free_encoder_structs",
     "lc3plus_enc_batch_create", "lc3plus_enc_batch_destroy", "lc3plus_enc_batch_input_samples",
     "lc3plus_enc_batch_num_bytes", "lc3plus_enc_batch_stride", "lc3plus_enc_batch_set_bitrate",
-    "lc3plus_enc_batch_set_bandwidth", "lc3plus_enc_batch_encode", "lc3plus_enc_batch_last_kernel_ms", "lc3plus_enc_batch_last_status",
+    "lc3plus_enc_batch_set_bandwidth", "lc3plus_enc_batch_encode", "lc3plus_enc_batch_last_kernel_ms", "lc3plus_enc_batch_last_status", "lc3plus_enc_batch_set_input_ready",
     "lc3plus_enc_init", "lc3plus_enc_set_frame_ms", "lc3plus_enc_set_hrmode", "lc3plus_enc_set_bitrate",
     "lc3plus_enc16", "lc3plus_enc_get_size",
     "lc3_dec_get_size", "lc3_dec_init", "lc3_dec_set_frame_ms", "lc3_dec_set_hrmode", "lc3_dec_get_output_samples",
@@ -58,6 +58,7 @@ def load_library():
         L.lc3plus_enc_batch_last_kernel_ms.restype = C.c_float
         L.lc3plus_enc_batch_last_kernel_ms.argtypes = [C.c_void_p]
         L.lc3plus_enc_batch_last_status.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.lc3plus_enc_batch_set_input_ready.argtypes = [C.c_void_p, C.c_int]
         for f in ("lc3plus_enc_batch_destroy", "lc3plus_enc_batch_input_samples", "lc3plus_enc_batch_stride"):
             getattr(L, f).argtypes = [C.c_void_p]
         L.lc3plus_enc_batch_num_bytes.argtypes = [C.c_void_p, C.c_int]
@@ -132,6 +133,13 @@ class Batch:
         if rc:
             raise LC3Error(rc, "lc3plus_enc_batch_encode(host)")
         return out
+
+    def set_input_ready(self, ready=True):
+        """Promise that the PCM of every following device-pointer call is complete when the call is made (include/lc3plus_batch.h):
+        consecutive calls then overlap (the next call's frame-parallel kernels beside this call's sequential tail)."""
+        rc = self.lib.lc3plus_enc_batch_set_input_ready(self.h, 1 if ready else 0)
+        if rc:
+            raise LC3Error(rc, "lc3plus_enc_batch_set_input_ready")
 
     def last_status(self, T):
         """uint8 [n_streams * channels, T]: LC3D_ENC_ST_* bits of the last call (0 = nothing the reference would assert on)."""

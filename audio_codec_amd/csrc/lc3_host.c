@@ -412,6 +412,12 @@ int lc3plus_enc_batch_last_status(lc3plus_batch* b, uint8_t* status, int max_ent
     return lc3hip_last_status(b->dev, status, max_entries);
 }
 
+LC3_Error lc3plus_enc_batch_set_input_ready(lc3plus_batch* b, int ready)
+{
+    if (!b) return LC3_NULL_ERROR;
+    return lc3hip_set_input_ready(b->dev, ready) ? LC3_ERROR : LC3_OK;
+}
+
 /* ------------------------------------------------------------------------------------------------ */
 /* single-stream drop-in API (R/lc3.h:163-295)                                                       */
 /* ------------------------------------------------------------------------------------------------ */

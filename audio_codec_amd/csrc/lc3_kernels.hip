@@ -2803,7 +2803,7 @@ extern "C" __global__ void lc3_encode_kernel_big(const lc3d_plan* __restrict__ P
                                                  uint8_t* __restrict__ status, int dT, int dt0, const float* __restrict__ spec, const float* __restrict__ frec,
                                                  const float* __restrict__ xnext);
 extern "C" __global__ void lc3_enc_front_kernel_big(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans, const float* __restrict__ state, const void* __restrict__ pcm,
-                                                    int bitdepth, int T, int tb, int nt, int fpw, int ncs, float* __restrict__ spec, float* __restrict__ rec, float* __restrict__ xnext);
+                                                    int bitdepth, int T, int tb, int nt, int fpw, int ncs, float* __restrict__ spec, float* __restrict__ rec, float* __restrict__ xnext, const float* __restrict__ xprev, int xprev_stride);
 extern "C" __global__ void lc3_enc_seq_kernel_big(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans, float* __restrict__ state, int T, int t0, int nt, int ncs,
                                                   int* __restrict__ dump, int dstride, int dT, int dt0, uint8_t* __restrict__ status, const float* __restrict__ spec,
                                                   const float* __restrict__ frec, const float* __restrict__ xnext);
@@ -2811,6 +2811,7 @@ extern "C" __global__ void lc3_enc_seq_kernel_big(const lc3d_plan* __restrict__ 
 #include "lc3_enc_snsvq.inc"
 #include "lc3_enc_pre.inc"
 #define LC3D_MAX_RUNS 16
+#define LC3D_AHEAD_MAX_RUNS 6         /* lc3hip_set_input_ready: calls of up to this many runs overlap with their predecessor */
 #define LC3D_RUN_FRAMES 4
 struct lc3hip_ctx {
     int device, ncs, n_streams, channels, N, big, state_words;
@@ -2819,7 +2820,8 @@ struct lc3hip_ctx {
     lc3d_trace* d_trace; size_t trace_cap;
     int* d_dump; size_t dump_cap; int hr, fused; float* d_y12; size_t y12_cap;
     uint8_t* d_status; size_t status_cap; int status_frames;
-    float* d_spec; size_t spec_cap; float* d_frec; size_t frec_cap; float* d_xnext; uint8_t* h_attack; int any_attack;   /* split path (lc3_enc_front.inc) */      /* per channel-frame status bits of the last call (LC3D_ENC_ST_*) */
+    float* d_spec; size_t spec_cap; float* d_frec; size_t frec_cap; float* d_xnext[2]; int xn_par; uint8_t* h_attack; int any_attack;
+    int input_ready, ahead_ok, ahead_T, ahead_R; hipEvent_t ev_s[LC3D_MAX_RUNS];   /* lc3hip_set_input_ready: side kernels of a call beside the previous call's tail */   /* split path (lc3_enc_front.inc) */      /* per channel-frame status bits of the last call (LC3D_ENC_ST_*) */
     /* host-pointer pipeline (lc3hip_encode_host): two chunk slots, each with device staging and (for pageable callers) pinned staging */
     void* hp_dpcm[2]; void* hp_pin_in[2]; size_t hp_pcm_cap, hp_pin_in_cap;
     hipStream_t s_h2d; hipEvent_t ev_h2d[2], ev_k[2];
@@ -2869,6 +2871,7 @@ extern "C" int lc3hip_reset_state(void* ctx, const float* init_state_one /* LC3D
     hipError_t e = hipMemcpy(c->d_state, h, sizeof(float) * sw * (size_t)c->ncs, hipMemcpyHostToDevice);
     free(h);
     HIPCHK(e);
+    c->ahead_ok = 0;                       /* the MDCT memory is in the state again, not in the hand-over of a previous call */
     return 0;
 }
 
@@ -2926,10 +2929,11 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
     const bool split = dy12 && ddump && !split_off;
     const int mc = c->big ? LC3D_MEMCAP_BIG : LC3D_MEMCAP_STD;
     if (!split) {
+        c->ahead_ok = 0;
         /* everything in lc3_encode_kernel (traced, diagnostic and very short launches), behind the 12.8 kHz pre-kernels when they apply */
         if (dy12) {
             const unsigned runs = (unsigned)((n_frames + PRE_FPW - 1) / PRE_FPW);
-            hipLaunchKernelGGL(lc3_enc_resample_kernel, dim3((unsigned)c->ncs * runs), dim3(WAVE), 0, s, c->d_plan, c->d_state, c->state_words, mc, dpcm, bitdepth, n_frames, 0, n_frames, c->ncs, dy12);
+            hipLaunchKernelGGL(lc3_enc_resample_kernel, dim3((unsigned)c->ncs * runs), dim3(WAVE), 0, s, c->d_plan, c->d_state, c->state_words, mc, dpcm, bitdepth, n_frames, 0, n_frames, c->ncs, dy12, c->d_state + LC3D_ST_XPREV, c->state_words);
             hipLaunchKernelGGL(lc3_enc_hp50_kernel, dim3((unsigned)((c->ncs + WAVE - 1) / WAVE)), dim3(WAVE), 0, s, c->d_plan, c->d_state, c->state_words, LC3D_ST_SCAL(mc), n_frames, 0, n_frames, c->ncs, dy12);
             HIPCHK(hipGetLastError());
         }
@@ -2945,11 +2949,11 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
         const size_t ns = (size_t)c->ncs * n_frames * c->N, nr = (size_t)c->ncs * n_frames * FR_WORDS;
         if (c->spec_cap < ns) { if (c->d_spec) HIPCHK(hipFree(c->d_spec)); c->d_spec = nullptr; c->spec_cap = 0; HIPCHK(hipMalloc((void**)&c->d_spec, ns * sizeof(float))); c->spec_cap = ns; }
         if (c->frec_cap < nr) { if (c->d_frec) HIPCHK(hipFree(c->d_frec)); c->d_frec = nullptr; c->frec_cap = 0; HIPCHK(hipMalloc((void**)&c->d_frec, nr * sizeof(float))); c->frec_cap = nr; }
-        if (!c->d_xnext) HIPCHK(hipMalloc((void**)&c->d_xnext, (size_t)c->ncs * mc * sizeof(float)));
+        for (int i = 0; i < 2; i++) if (!c->d_xnext[i]) HIPCHK(hipMalloc((void**)&c->d_xnext[i], (size_t)c->ncs * mc * sizeof(float)));
         if (!c->s_pre) {
             HIPCHK(hipStreamCreateWithFlags(&c->s_pre, hipStreamNonBlocking)); HIPCHK(hipStreamCreateWithFlags(&c->s_fr, hipStreamNonBlocking));
             HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-            for (int i = 0; i < LC3D_MAX_RUNS; i++) { HIPCHK(hipEventCreateWithFlags(&c->ev_p[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_f[i], hipEventDisableTiming)); }
+            for (int i = 0; i < LC3D_MAX_RUNS; i++) { HIPCHK(hipEventCreateWithFlags(&c->ev_p[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_f[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_s[i], hipEventDisableTiming)); }
         }
         float* dspec = c->d_spec; float* dfrec = c->d_frec;
         int R = (n_frames + LC3D_RUN_FRAMES - 1) / LC3D_RUN_FRAMES;              /* runs of LC3D_RUN_FRAMES frames */
@@ -2957,8 +2961,21 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
         if (R < 1) R = 1;
         { const char* e = getenv("LC3PLUS_ENC_RUNS"); if (e && atoi(e) >= 1 && atoi(e) <= LC3D_MAX_RUNS) R = atoi(e); }     /* diagnostic */
         const int Tr = (n_frames + R - 1) / R;
-        HIPCHK(hipEventRecord(c->ev_fork, s));
-        HIPCHK(hipStreamWaitEvent(c->s_pre, c->ev_fork, 0)); HIPCHK(hipStreamWaitEvent(c->s_fr, c->ev_fork, 0));
+        /* Where the side kernels of this call may start.  Normally behind everything the caller queued on s before the call (the PCM may
+         * come from there).  With lc3hip_set_input_ready - the PCM of a call is complete when the call is made - and a previous call of
+         * the same shape on the same stream, they need not wait for that call's sequential tail and bitstream writer: their streams
+         * carry on in their own order; the kernels of run k wait for the previous call's rate kernel of run k, the last reader of the
+         * hand-over rows they overwrite; the MDCT memory before frame 0 is read from the previous call's hand-over (two alternating
+         * buffers), not from the state that call's last rate kernel is still to update. */
+        /* Measured (bench.py --frames F with / without --serial-calls, Mframes/s): 12 frames 55.9 / 47.2, 16: 56.7 / 51.4, 24: 60.6 / 58.5,
+         * 32: 61.8 / 61.8, 64: 64.6 / 68.2 - a long call loses more to the bitstream writer sharing the chip with the next call's side
+         * kernels than it gains at its ends, so the overlap is taken for calls of up to LC3D_AHEAD_MAX_RUNS runs. */
+        const bool ahead = c->input_ready && R <= LC3D_AHEAD_MAX_RUNS && c->ahead_ok && c->ahead_T == n_frames && c->ahead_R == R && c->last_stream == s && dt0 == 0 && dT == n_frames && pack;
+        float* xn_w = c->d_xnext[c->xn_par];                         /* written by this call's front kernel */
+        const float* xprev = ahead ? c->d_xnext[c->xn_par ^ 1] : c->d_state + LC3D_ST_XPREV;
+        const int xprev_stride = ahead ? mc : c->state_words;
+        if (!ahead) { HIPCHK(hipEventRecord(c->ev_fork, s)); HIPCHK(hipStreamWaitEvent(c->s_pre, c->ev_fork, 0)); HIPCHK(hipStreamWaitEvent(c->s_fr, c->ev_fork, 0)); }
+        else HIPCHK(hipStreamWaitEvent(c->s_pre, c->ev_f[R - 1], 0));    /* the resampler reads the hand-over the previous call's last front kernel wrote */
         /* The 12.8 kHz pre-kernels run ahead in larger pieces than the runs: the HP50 kernel (one stream per lane, B / 64 waves) costs ~0.1 ms
          * per launch whatever the frame count, which per run would make its stream the slowest.  First piece = the first run (the rate
          * kernel should start early), then four runs at a time, in stream order between the pitch kernels that need them.  (More side
@@ -2966,10 +2983,11 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
          * one run back to back.) */
         for (int k = 0, tb = 0, hb = 0, hk = 0; tb < n_frames; k++, tb += Tr) {
             const int nt = n_frames - tb < Tr ? n_frames - tb : Tr;
+            if (ahead) { HIPCHK(hipStreamWaitEvent(c->s_pre, c->ev_s[k], 0)); HIPCHK(hipStreamWaitEvent(c->s_fr, c->ev_s[k], 0)); }
             if (tb >= hb) {
                 const int hn0 = hk == 0 ? Tr : 4 * Tr, hn = n_frames - hb < hn0 ? n_frames - hb : hn0;
                 const unsigned pruns = (unsigned)((hn + PRE_FPW - 1) / PRE_FPW);
-                hipLaunchKernelGGL(lc3_enc_resample_kernel, dim3((unsigned)c->ncs * pruns), dim3(WAVE), 0, c->s_pre, c->d_plan, c->d_state, c->state_words, mc, dpcm, bitdepth, n_frames, hb, hn, c->ncs, dy12);
+                hipLaunchKernelGGL(lc3_enc_resample_kernel, dim3((unsigned)c->ncs * pruns), dim3(WAVE), 0, c->s_pre, c->d_plan, c->d_state, c->state_words, mc, dpcm, bitdepth, n_frames, hb, hn, c->ncs, dy12, xprev, xprev_stride);
                 hipLaunchKernelGGL(lc3_enc_hp50_kernel, dim3((unsigned)((c->ncs + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->s_pre, c->d_plan, c->d_state, c->state_words, LC3D_ST_SCAL(mc), n_frames, hb, hn, c->ncs, dy12);
                 HIPCHK(hipGetLastError());
                 hb += hn; hk++;
@@ -2979,8 +2997,8 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
             HIPCHK(hipEventRecord(c->ev_p[k], c->s_pre));
             const int fpw = nt < FRONT_FPW ? nt : FRONT_FPW;
             const unsigned fruns = (unsigned)((nt + fpw - 1) / fpw);
-            if (c->big) hipLaunchKernelGGL(lc3_enc_front_kernel_big, dim3((unsigned)c->ncs * fruns), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames, tb, nt, fpw, c->ncs, dspec, dfrec, c->d_xnext);
-            else hipLaunchKernelGGL(lc3_enc_front_kernel, dim3((unsigned)c->ncs * fruns), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames, tb, nt, fpw, c->ncs, dspec, dfrec, c->d_xnext);
+            if (c->big) hipLaunchKernelGGL(lc3_enc_front_kernel_big, dim3((unsigned)c->ncs * fruns), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames, tb, nt, fpw, c->ncs, dspec, dfrec, xn_w, xprev, xprev_stride);
+            else hipLaunchKernelGGL(lc3_enc_front_kernel, dim3((unsigned)c->ncs * fruns), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames, tb, nt, fpw, c->ncs, dspec, dfrec, xn_w, xprev, xprev_stride);
             if (c->any_attack)
                 hipLaunchKernelGGL(lc3_enc_attack_kernel, dim3((unsigned)((c->ncs + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, c->state_words, LC3D_ST_SCAL(mc), dfrec, n_frames, tb, nt, c->ncs);
             const long long nfr = (long long)c->ncs * nt;
@@ -2988,10 +3006,12 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(c->ev_f[k], c->s_fr));
             HIPCHK(hipStreamWaitEvent(s, c->ev_p[k], 0)); HIPCHK(hipStreamWaitEvent(s, c->ev_f[k], 0));
-            if (c->big) hipLaunchKernelGGL(lc3_enc_seq_kernel_big, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, n_frames, tb, nt, c->ncs, ddump, dstride, dT, dt0, c->d_status, dspec, dfrec, c->d_xnext);
-            else hipLaunchKernelGGL(lc3_enc_seq_kernel, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, n_frames, tb, nt, c->ncs, ddump, dstride, dT, dt0, c->d_status, dspec, dfrec, c->d_xnext);
+            if (c->big) hipLaunchKernelGGL(lc3_enc_seq_kernel_big, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, n_frames, tb, nt, c->ncs, ddump, dstride, dT, dt0, c->d_status, dspec, dfrec, xn_w);
+            else hipLaunchKernelGGL(lc3_enc_seq_kernel, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, n_frames, tb, nt, c->ncs, ddump, dstride, dT, dt0, c->d_status, dspec, dfrec, xn_w);
             HIPCHK(hipGetLastError());
+            if (c->input_ready && R <= LC3D_AHEAD_MAX_RUNS) HIPCHK(hipEventRecord(c->ev_s[k], s));
         }
+        c->ahead_ok = (dt0 == 0 && dT == n_frames && pack) ? 1 : 0; c->ahead_T = n_frames; c->ahead_R = R; c->xn_par ^= 1;
     }
     if (ddump && pack) {
         HIPCHK(hipGetLastError());
@@ -3118,6 +3138,14 @@ extern "C" int lc3hip_last_status(void* ctx, uint8_t* status_host, int n)
     return n;
 }
 
+extern "C" int lc3hip_set_input_ready(void* ctx, int ready)
+{
+    lc3hip_ctx* c = (lc3hip_ctx*)ctx;
+    if (!c) return 1;
+    c->input_ready = ready != 0; c->ahead_ok = 0;
+    return 0;
+}
+
 extern "C" float lc3hip_last_ms(void* ctx)
 {
     lc3hip_ctx* c = (lc3hip_ctx*)ctx;
@@ -3143,7 +3171,7 @@ extern "C" int lc3hip_destroy(void* ctx)
     if (c->d_status) hipFree(c->d_status);
     if (c->d_spec) hipFree(c->d_spec);
     if (c->d_frec) hipFree(c->d_frec);
-    if (c->d_xnext) hipFree(c->d_xnext);
+    for (int i = 0; i < 2; i++) if (c->d_xnext[i]) hipFree(c->d_xnext[i]);
     free(c->h_attack);
     for (int i = 0; i < 2; i++) {
         if (c->hp_dpcm[i]) hipFree(c->hp_dpcm[i]);
@@ -3153,7 +3181,7 @@ extern "C" int lc3hip_destroy(void* ctx)
     }
     if (c->s_h2d) hipStreamDestroy(c->s_h2d);
     if (c->s_pre) { hipStreamDestroy(c->s_pre); hipStreamDestroy(c->s_fr); hipEventDestroy(c->ev_fork);
-                    for (int i = 0; i < LC3D_MAX_RUNS; i++) { hipEventDestroy(c->ev_p[i]); hipEventDestroy(c->ev_f[i]); } }
+                    for (int i = 0; i < LC3D_MAX_RUNS; i++) { hipEventDestroy(c->ev_p[i]); hipEventDestroy(c->ev_f[i]); hipEventDestroy(c->ev_s[i]); } }
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); }

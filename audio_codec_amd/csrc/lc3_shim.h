@@ -35,6 +35,7 @@ int   lc3hip_upload_chans(void* ctx, const lc3d_chan* chans, int first, int coun
 int   lc3hip_encode(void* ctx, const void* pcm, int pcm_on_device, int bitdepth, int n_frames, void* out, int out_stride,
                     int out_on_device, void* hip_stream, int sync, void* trace_host);
 float lc3hip_last_ms(void* ctx);
+int   lc3hip_set_input_ready(void* ctx, int ready);              /* see lc3plus_enc_batch_set_input_ready (include/lc3plus_batch.h) */
 int   lc3hip_last_status(void* ctx, uint8_t* status_host, int n);   /* LC3D_ENC_ST_* bits per channel-frame of the last call; returns the count copied */
 int   lc3hip_destroy(void* ctx);
 #ifdef __cplusplus

@@ -160,6 +160,7 @@ def main():
     ap.add_argument("--frames", type=int, default=0, help="frames per stream per step (default: the workload's; c1: 64, SURVEY 8(d))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the host-I/O and T = 1 side measurements of the default line")
+    ap.add_argument("--serial-calls", action="store_true", help="encoder: do not declare the PCM ready ahead of the calls (no overlap between consecutive calls)")
     ap.add_argument("--workload", default="c1", choices=sorted(WORKLOADS), help="c1 = BASELINE configs[1] (the metric's configuration)")
     a = ap.parse_args()
 
@@ -208,6 +209,8 @@ def main():
         back = torch.zeros(B, T, ch, n, dtype=torch.int16, device=dev)
         step = lambda: dec.decode_device(out.data_ptr(), stride, T, back.data_ptr(), 16, hip_stream=stream.cuda_stream)
     else:
+        # the PCM is resident and complete before the timed region: say so, and consecutive calls overlap (include/lc3plus_batch.h)
+        batch.set_input_ready(not a.serial_calls)
         step = lambda: batch.encode_device(pcm.data_ptr(), 16, T, out.data_ptr(), stride, hip_stream=stream.cuda_stream, sync=False)
 
     # HIP events on the launch stream around the timed region -> average launch duration (all kernels of one call)
@@ -243,7 +246,8 @@ def main():
             "config": {"workload": "%s = %s; %d streams x %d frames per step per GPU" % (a.workload, what, B, T),
                        "streams_per_gpu": B, "frames_per_step": T, "channels": ch, "bytes_per_frame": sorted(set(nbl)),
                        "stereo_frames_per_step_all_gpus": B * T * world if ch == 2 else None,
-                       "parallelism": "streams sharded over %d GPU(s) by contiguous blocks, no collectives" % world},
+                       "parallelism": "streams sharded over %d GPU(s) by contiguous blocks, no collectives" % world,
+                       "input_ready": (not decode and not a.serial_calls)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": prof.get("traffic_bytes"),
                          "kernel": kernels + " (one call = these launches; HIP events on the launch stream around all of them)",
@@ -260,6 +264,13 @@ def main():
                                     "frac": round(ach / peak, 4), "valu_insts_per_launch": prof["valu_insts"], "clock_ghz": clk,
                                     "lane_utilisation": prof.get("valu_lane_util"),
                                     "source": "profiles/%s_counters.json (SQ_INSTS_VALU, separate rocprofv3 --pmc pass of this command)" % PROFILE_ROUND}
+        if not decode and not a.no_extras and not a.serial_calls:
+            # the same steps without the input-ready promise: every call waits for the previous one to drain
+            batch.set_input_ready(False)
+            ws = timed_steps(step, a.steps, a.warmup, lambda: torch.cuda.synchronize(dev))
+            batch.set_input_ready(True)
+            res["serial_calls"] = {"value": round(units * a.steps / ws / 1e6, 4), "unit": "Mframes/s", "ms_per_step": round(ws / a.steps * 1e3, 4),
+                                   "note": "rank 0, lc3plus_enc_batch_set_input_ready(0): the side kernels of a call wait for everything queued before it"}
         if a.workload == "c1" and not a.no_extras:
             # (1) the same workload through host pointers: pinned staging + chunked H2D / kernels / D2H (PCIe-inclusive; never `value`)
             h_pcm = torch.empty(pcm.shape, dtype=torch.int16, pin_memory=True); h_pcm.copy_(pcm)

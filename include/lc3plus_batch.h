@@ -42,6 +42,14 @@ LC3_Error lc3plus_enc_batch_encode(lc3plus_batch* batch, const void* pcm, int pc
                                    int n_frames, void* out, int out_stride, int out_on_device,
                                    void* hip_stream, int sync);
 
+/* A promise about device-pointer calls, off by default: with ready != 0 the caller guarantees that the PCM passed to every following
+ * encode() call is COMPLETE in device memory when the call is made - not merely queued earlier on hip_stream (so it is wrong for PCM
+ * that a kernel or copy queued on hip_stream is still producing).  The batch then lets the frame-parallel and pitch kernels of a
+ * call start on its own streams while the sequential tail and the bitstream writer of the previous call on the same hip_stream are
+ * still running (consecutive calls of equal n_frames, taken for calls of up to 24 frames, where it pays); results are identical, and the output of a call is complete in stream order
+ * on hip_stream as before.  Streaming servers that fill their PCM ring ahead of the encode calls are the use. */
+LC3_Error lc3plus_enc_batch_set_input_ready(lc3plus_batch* batch, int ready);
+
 /* Kernel-only timing of the last encode() call in milliseconds (HIP events on the launch stream). */
 float lc3plus_enc_batch_last_kernel_ms(lc3plus_batch* batch);
 

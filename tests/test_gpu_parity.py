@@ -504,6 +504,78 @@ def test_attack_detector_on_the_split_path():
             assert (g[0, k, :o.nbytes] == o.encode(pcm[3, t0 + k][None])).all(), (t0, k)
 
 
+class _Dev:
+    """Device buffers through ctypes (hipMalloc / hipMemcpy): the tests do not depend on torch."""
+    def __init__(self):
+        import ctypes as C
+        self.C = C; self.hip = C.CDLL("libamdhip64.so"); self.ptrs = []
+    def put(self, arr):
+        C = self.C; arr = np.ascontiguousarray(arr); p = C.c_void_p()
+        assert self.hip.hipMalloc(C.byref(p), C.c_size_t(arr.nbytes)) == 0
+        assert self.hip.hipMemcpy(p, C.c_void_p(arr.ctypes.data), C.c_size_t(arr.nbytes), C.c_int(1)) == 0
+        self.ptrs.append(p); return p.value
+    def zeros(self, nbytes):
+        C = self.C; p = C.c_void_p()
+        assert self.hip.hipMalloc(C.byref(p), C.c_size_t(nbytes)) == 0 and self.hip.hipMemset(p, 0, C.c_size_t(nbytes)) == 0
+        self.ptrs.append(p); return p.value
+    def get(self, ptr, shape, dtype):
+        C = self.C; out = np.zeros(shape, dtype)
+        assert self.hip.hipMemcpy(C.c_void_p(out.ctypes.data), C.c_void_p(ptr), C.c_size_t(out.nbytes), C.c_int(2)) == 0
+        return out
+    def sync(self):
+        assert self.hip.hipDeviceSynchronize() == 0
+    def free(self):
+        for p in self.ptrs: self.hip.hipFree(p)
+        self.ptrs = []
+
+
+@pytest.mark.parametrize("B,T,K,rates", [(1024, 16, 6, [64000]), (512, 12, 5, [64000, 96000, 128000, 32000, 256000]), (4096, 24, 3, [64000])])
+def test_consecutive_calls_overlap_with_input_ready(B, T, K, rates):
+    """lc3plus_enc_batch_set_input_ready: K device-pointer calls queued back to back without a host synchronisation in between - the side
+    kernels of call k+1 run beside the sequential tail and the bitstream writer of call k, wait per run for the previous call's rate
+    kernel, and take the MDCT memory from the previous call's hand-over - give the bytes of one continuous encode (oracle on a sample
+    of streams for the large case).  Then: a call of another length (takes the ordered path), a bitrate switch between overlapped
+    calls, and the promise withdrawn again."""
+    amd = _amd()
+    d = _Dev()
+    try:
+        TT = T * K + 7 + 2 * T
+        pcm = synth_pcm(B, TT, 480, 48000, seed=2024 + B)
+        br = [rates[i % len(rates)] for i in range(B)]
+        b = amd.Batch(B, 48000, 1, 10.0, 0, br, device=0)
+        stride = b.stride
+        b.set_input_ready(True)
+        cuts = [T] * K + [7] + [T, T]
+        ins, outs, t0 = [], [], 0
+        for n in cuts:
+            ins.append(d.put(pcm[:, t0:t0 + n])); outs.append(d.zeros(B * n * stride)); t0 += n
+        d.sync()                                          # the promise: all PCM is on the device before the first call
+        for k in range(K + 1):
+            b.encode_device(ins[k], 16, cuts[k], outs[k], stride, hip_stream=None, sync=False)
+        b.encode_device(ins[K + 1], 16, T, outs[K + 1], stride, hip_stream=None, sync=False)      # same length as before the odd call: ordered, then
+        sw = B // 2
+        new_br = 32000 if br[sw] != 32000 else 48000
+        assert b.set_bitrate(sw, new_br) == 0                                                       # (drains the stream)
+        b.set_input_ready(False)
+        b.encode_device(ins[K + 2], 16, T, outs[K + 2], stride, hip_stream=None, sync=True)
+        got = np.concatenate([d.get(outs[k], (B, cuts[k], stride), np.uint8) for k in range(len(cuts))], axis=1)
+        assert not b.last_status(T).any()
+        pick = list(range(B)) if B <= 1024 else sorted(set([0, 1, B - 1, sw] + [int(v) for v in np.random.default_rng(3).choice(B, 60, replace=False)]))
+        pick = [i for i in pick if i != sw]
+        want = _oracle_batch(pcm[pick], 48000, 10.0, 0, [br[i] for i in pick], stride)
+        nb = [b.num_bytes(i) for i in pick]
+        bad = [(i, t) for k, i in enumerate(pick) for t in range(TT) if (got[i, t, :nb[k]] != want[k, t, :nb[k]]).any()]
+        assert not bad, (len(bad), bad[:8])
+        # the switched stream: continuous up to the switch, then the oracle with the same switch
+        o = Oracle(48000, 1, 10.0, 0, br[sw], portable_math=True)
+        for t in range(TT):
+            if t == TT - T: assert o.set_bitrate(new_br) == 0
+            w = o.encode(pcm[sw, t][None])
+            assert (got[sw, t, :len(w)] == w).all(), t
+    finally:
+        d.free()
+
+
 def test_full_size_baseline_batch_properties():
     """BASELINE configs[1] at its full size (4096 mono streams x 64 frames, 48 kHz / 10 ms / 64 kbps) through size-independent properties:
     (1) streams are independent - 512 distinct streams tiled 8 times in a shuffled order give 8 identical copies of every output;
