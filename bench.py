@@ -254,6 +254,15 @@ def main():
                          "kernel_ms_avg": round(kern_ms, 4), "algorithmic_bytes_per_launch": algo,
                          "note": "not HBM bound (SURVEY 8d): see roofline_valu and DESIGN.md section 5"},
         }
+        if prof.get("traffic_bytes"):
+            # what the hand-overs between the kernels cost: measured HBM traffic of one call over the call's duration, against the same peak
+            tr = prof["traffic_bytes"] / (kern_ms * 1e-3) / 1e9
+            res["roofline"]["traffic_gbps"] = round(tr, 1)
+            res["roofline"]["traffic_frac"] = round(tr / HBM_PEAK_GBS, 4)
+            if decode:
+                res["roofline"]["note"] = ("algorithmic bytes are 1.4 % of the HBM peak, the measured traffic (hand-over rows between the four kernels) "
+                                           "%.0f %%: the parse kernel (the longest) is bound by its per-lane instruction stream under divergence "
+                                           "(lane utilisation in roofline_valu), the IMDCT and synthesis kernels move 2.6 GB in 1.4 ms; DESIGN.md section 8" % (100 * tr / HBM_PEAK_GBS))
         if prof.get("valu_insts"):
             # second roofline object: wave-level VALU instruction issue.  peak = 1024 SIMDs x clock / 2 cycles per wave64 VALU op
             # (MI355X_MICROARCH.md constants table: v_fma_f32 wave64 2 cycles on a SIMD-32 with co-resident waves)
