@@ -1941,14 +1941,26 @@ template <class LdsT> STAGE void st_quantize(const lc3d_plan* __restrict__ P, co
     const float gain = unif(L.fsc[F_GAIN]);
     int* xq = XQ(L); uint32_t* cdw = CDW(L);
     SUB_BEGIN();
-    /* compile-time loop bound: the (long) division sequences of a lane's lines are independent and interleave */
+    /* xq = (int)(x / gain + offs * sign(x)), R/quantize_spec.c:37-47.  The division is an IEEE one per line in the reference; here the line
+     * is first multiplied by 1 / gain (one division per frame): product and sum are within 3e-7 relative of the reference's, so the
+     * truncation agrees unless the sum lies that close to an integer - then (a few lines per thousand frames) the line is divided. */
+    const float rgain = 1.0f / gain;
+    unsigned amb = 0;
 #pragma unroll
     for (int k = 0; k < MAXN / WAVE + 1; k++) {
         const int i = lane + 64 * k;
         if (i < nt) {
             const float x = L.A[i];
-            const int sg = x > 0 ? 1 : x < 0 ? -1 : 0;
-            xq[i] = (int)truncf(x / gain + offs * (float)sg);
+            const float o = x > 0 ? offs : x < 0 ? -offs : 0.0f;
+            const float v = x * rgain + o;
+            xq[i] = (int)v;
+            if (x != 0 && fabsf(v - rintf(v)) <= fabsf(v) * 5e-7f) amb |= 1u << k;
+        }
+    }
+    if (__ballot(amb != 0)) {
+#pragma unroll
+        for (int k = 0; k < MAXN / WAVE + 1; k++) {
+            if ((amb >> k) & 1u) { const int i = lane + 64 * k; const float x = L.A[i]; xq[i] = (int)truncf(x / gain + (x > 0 ? offs : -offs)); }
         }
     }
     int rate = 0;
