@@ -529,8 +529,16 @@ class _Dev:
         self.ptrs = []
 
 
-@pytest.mark.parametrize("B,T,K,rates", [(1024, 16, 6, [64000]), (512, 12, 5, [64000, 96000, 128000, 32000, 256000]), (4096, 24, 3, [64000])])
-def test_consecutive_calls_overlap_with_input_ready(B, T, K, rates):
+@pytest.mark.parametrize("fs,ms,hr,N,B,T,K,rates", [
+    (48000, 10.0, 0, 480, 1024, 16, 6, [64000]),
+    (48000, 10.0, 0, 480, 512, 12, 5, [64000, 96000, 128000, 32000, 256000]),       # attack handling from 100 bytes: the detector's kernel and state
+    (48000, 10.0, 0, 480, 4096, 24, 3, [64000]),
+    (32000, 10.0, 0, 320, 256, 16, 4, [96000, 64000, 128000]),                        # attack handling from 81 bytes
+    (16000, 5.0, 0, 80, 256, 20, 4, [32000, 64000]),
+    (96000, 10.0, 1, 960, 64, 12, 4, [256000, 400000]),                               # the large-layout kernels
+    (48000, 2.5, 0, 120, 256, 24, 4, [128000, 64000]),
+])
+def test_consecutive_calls_overlap_with_input_ready(fs, ms, hr, N, B, T, K, rates):
     """lc3plus_enc_batch_set_input_ready: K device-pointer calls queued back to back without a host synchronisation in between - the side
     kernels of call k+1 run beside the sequential tail and the bitstream writer of call k, wait per run for the previous call's rate
     kernel, and take the MDCT memory from the previous call's hand-over - give the bytes of one continuous encode (oracle on a sample
@@ -540,9 +548,9 @@ def test_consecutive_calls_overlap_with_input_ready(B, T, K, rates):
     d = _Dev()
     try:
         TT = T * K + 7 + 2 * T
-        pcm = synth_pcm(B, TT, 480, 48000, seed=2024 + B)
+        pcm = synth_pcm(B, TT, N, fs, seed=2024 + B)
         br = [rates[i % len(rates)] for i in range(B)]
-        b = amd.Batch(B, 48000, 1, 10.0, 0, br, device=0)
+        b = amd.Batch(B, fs, 1, ms, hr, br, device=0)
         stride = b.stride
         b.set_input_ready(True)
         cuts = [T] * K + [7] + [T, T]
@@ -553,8 +561,8 @@ def test_consecutive_calls_overlap_with_input_ready(B, T, K, rates):
         for k in range(K + 1):
             b.encode_device(ins[k], 16, cuts[k], outs[k], stride, hip_stream=None, sync=False)
         b.encode_device(ins[K + 1], 16, T, outs[K + 1], stride, hip_stream=None, sync=False)      # same length as before the odd call: ordered, then
-        sw = B // 2
-        new_br = 32000 if br[sw] != 32000 else 48000
+        sw = next(i for i in range(B // 2, B) if len(rates) == 1 or br[i] != min(rates))
+        new_br = min(rates) if len(rates) > 1 else 48000
         assert b.set_bitrate(sw, new_br) == 0                                                       # (drains the stream)
         b.set_input_ready(False)
         b.encode_device(ins[K + 2], 16, T, outs[K + 2], stride, hip_stream=None, sync=True)
@@ -562,12 +570,12 @@ def test_consecutive_calls_overlap_with_input_ready(B, T, K, rates):
         assert not b.last_status(T).any()
         pick = list(range(B)) if B <= 1024 else sorted(set([0, 1, B - 1, sw] + [int(v) for v in np.random.default_rng(3).choice(B, 60, replace=False)]))
         pick = [i for i in pick if i != sw]
-        want = _oracle_batch(pcm[pick], 48000, 10.0, 0, [br[i] for i in pick], stride)
+        want = _oracle_batch(pcm[pick], fs, ms, hr, [br[i] for i in pick], stride)
         nb = [b.num_bytes(i) for i in pick]
         bad = [(i, t) for k, i in enumerate(pick) for t in range(TT) if (got[i, t, :nb[k]] != want[k, t, :nb[k]]).any()]
         assert not bad, (len(bad), bad[:8])
         # the switched stream: continuous up to the switch, then the oracle with the same switch
-        o = Oracle(48000, 1, 10.0, 0, br[sw], portable_math=True)
+        o = Oracle(fs, 1, ms, hr, br[sw], portable_math=True)
         for t in range(TT):
             if t == TT - T: assert o.set_bitrate(new_br) == 0
             w = o.encode(pcm[sw, t][None])
