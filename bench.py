@@ -260,7 +260,7 @@ def main():
             res["roofline"]["traffic_gbps"] = round(tr, 1)
             res["roofline"]["traffic_frac"] = round(tr / HBM_PEAK_GBS, 4)
             if decode:
-                res["roofline"]["note"] = ("algorithmic bytes are 1.4 % of the HBM peak, the measured traffic (hand-over rows between the four kernels) "
+                res["roofline"]["note"] = ("algorithmic bytes are 1.4 %% of the HBM peak, the measured traffic (hand-over rows between the four kernels) "
                                            "%.0f %%: the parse kernel (the longest) is bound by its per-lane instruction stream under divergence "
                                            "(lane utilisation in roofline_valu), the IMDCT and synthesis kernels move 2.6 GB in 1.4 ms; DESIGN.md section 8" % (100 * tr / HBM_PEAK_GBS))
         if prof.get("valu_insts"):
