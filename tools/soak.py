@@ -1,5 +1,5 @@
 """Differential soak (GPU box): every operating point x several seeds, GPU frames against the oracle's batch entry (same math).
-Usage: python tools/soak.py [seeds] [streams] [frames]   -> prints one line per configuration and a total; exit code 1 on any difference."""
+Usage: [SOAK_READY=frames_per_call] python tools/soak.py [seeds] [streams] [frames]   -> prints one line per configuration and a total; exit code 1 on any difference."""
 import ctypes as C, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,6 +9,32 @@ from lc3_harness import synth_pcm, ORACLE_DIR
 
 L = C.CDLL(os.path.join(ORACLE_DIR, "liblc3_oracle_pm.so"))
 L.lc3o_encode_batch16.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+READY = int(os.environ.get("SOAK_READY", "0"))            # frames per call of the overlapped variant (0: host-pointer calls)
+HIP = C.CDLL("libamdhip64.so") if READY else None
+
+
+def encode_ready(b, pcm, tc):
+    B, T = pcm.shape[:2]
+    stride = b.stride
+    b.set_input_ready(True)
+    ptrs, calls = [], []
+    for t0 in range(0, T, tc):
+        n = min(tc, T - t0)
+        a = np.ascontiguousarray(pcm[:, t0:t0 + n]); pi, po = C.c_void_p(), C.c_void_p()
+        assert HIP.hipMalloc(C.byref(pi), C.c_size_t(a.nbytes)) == 0 and HIP.hipMalloc(C.byref(po), C.c_size_t(B * n * stride)) == 0
+        assert HIP.hipMemcpy(pi, C.c_void_p(a.ctypes.data), C.c_size_t(a.nbytes), C.c_int(1)) == 0 and HIP.hipMemset(po, 0, C.c_size_t(B * n * stride)) == 0
+        ptrs += [pi, po]; calls.append((pi.value, po.value, n))
+    assert HIP.hipDeviceSynchronize() == 0
+    for pi, po, n in calls: b.encode_device(pi, 16, n, po, stride, hip_stream=None, sync=False)
+    outs = []
+    for pi, po, n in calls:
+        o = np.zeros((B, n, stride), np.uint8)
+        assert HIP.hipMemcpy(C.c_void_p(o.ctypes.data), C.c_void_p(po), C.c_size_t(o.nbytes), C.c_int(2)) == 0
+        outs.append(o)
+    for p in ptrs: HIP.hipFree(p)
+    return np.concatenate(outs, axis=1)
+
+
 def configurations():
     cfg = []
     for fs in (8000, 16000, 24000, 32000, 44100, 48000):
@@ -31,7 +57,10 @@ def run(NS, B, T, verbose=True):
             br = np.array([rates[(i + seed) % len(rates)] for i in range(B)], np.int32)
             pcm = synth_pcm(B, T, N, fs, seed=4000 + 17 * seed)
             b = audio_codec_amd.Batch(B, fs, 1, ms, hr, list(map(int, br)), device=0)
-            got = np.concatenate([b.encode(pcm[:, :T // 3]), b.encode(pcm[:, T // 3:])], axis=1)
+            if READY:     # device pointers, the input-ready promise, calls of READY frames queued back to back (consecutive calls overlap)
+                got = encode_ready(b, pcm, READY)
+            else:
+                got = np.concatenate([b.encode(pcm[:, :T // 3]), b.encode(pcm[:, T // 3:])], axis=1)
             want = np.zeros_like(got)
             rc = L.lc3o_encode_batch16(fs, ms, hr, B, T, br.ctypes.data, np.ascontiguousarray(pcm).ctypes.data, want.ctypes.data, b.stride)
             assert rc == 0, rc
