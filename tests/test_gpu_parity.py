@@ -586,6 +586,35 @@ def test_consecutive_calls_overlap_with_input_ready(fs, ms, hr, N, B, T, K, rate
         d.free()
 
 
+def test_consecutive_stereo_calls_overlap_with_input_ready():
+    """The same for stereo pairs (BASELINE configs[2]'s shape: two channel-streams per stream, one frame of both per payload), calls of
+    16 frames queued back to back under the promise, odd byte split (61.6 kbps: 77 = 39 + 38 bytes) among the rates."""
+    amd = _amd()
+    d = _Dev()
+    try:
+        B, T, K = 384, 16, 5
+        rates = [128000, 61600, 96000]
+        rng = np.random.default_rng(77)
+        mono = synth_pcm(2 * B, T * K, 480, 48000, seed=515)
+        pcm = np.ascontiguousarray(mono.reshape(B, 2, T * K, 480).transpose(0, 2, 1, 3))       # [pair, T, ch, N]
+        br = [rates[i % len(rates)] for i in range(B)]
+        b = amd.Batch(B, 48000, 2, 10.0, 0, br, device=0)
+        stride = b.stride
+        b.set_input_ready(True)
+        ins = [d.put(pcm[:, k * T:(k + 1) * T]) for k in range(K)]
+        outs = [d.zeros(B * T * stride) for _ in range(K)]
+        d.sync()
+        for k in range(K): b.encode_device(ins[k], 16, T, outs[k], stride, hip_stream=None, sync=False)
+        got = np.concatenate([d.get(outs[k], (B, T, stride), np.uint8) for k in range(K)], axis=1)
+        assert not b.last_status(T).any()
+        want = _oracle_batch_ch(pcm, 48000, 10.0, 0, 2, br, stride)
+        nb = [b.num_bytes(i) for i in range(B)]
+        bad = [(i, t) for i in range(B) for t in range(T * K) if (got[i, t, :nb[i]] != want[i, t, :nb[i]]).any()]
+        assert not bad, (len(bad), bad[:8])
+    finally:
+        d.free()
+
+
 def test_full_size_baseline_batch_properties():
     """BASELINE configs[1] at its full size (4096 mono streams x 64 frames, 48 kHz / 10 ms / 64 kbps) through size-independent properties:
     (1) streams are independent - 512 distinct streams tiled 8 times in a shuffled order give 8 identical copies of every output;
