@@ -273,6 +273,18 @@ def main():
                                     "frac": round(ach / peak, 4), "valu_insts_per_launch": prof["valu_insts"], "clock_ghz": clk,
                                     "lane_utilisation": prof.get("valu_lane_util"),
                                     "source": "profiles/%s_counters.json (SQ_INSTS_VALU, separate rocprofv3 --pmc pass of this command)" % PROFILE_ROUND}
+            # what this instruction mix is actually up against: wave-instructions of the counted kinds (vector, scalar, LDS, vector memory)
+            # issued per SIMD cycle, next to the rate at which a SIMD issues co-resident DEPENDENT chains (tools/ubench/issue.hip,
+            # profiles/r02_issue_rate.txt: one v_fma per 4.0 cycles with four such waves, 2.95 with eight).  One wave per stream and
+            # 4096 streams on 1024 SIMDs are four serial chains per SIMD; the kernels beside them add a fifth and sixth.
+            pk = prof.get("per_kernel") or {}
+            counted = sum(v.get(c, 0) for v in pk.values() for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD"))
+            if counted:
+                per_cycle = counted / 1024.0 / (kern_ms * 1e-3 * clk * 1e9)
+                res["roofline_valu"]["issue"] = {"insts_per_simd_cycle": round(per_cycle, 3), "counted_insts_per_launch": int(counted),
+                                                 "dependent_chains_4_waves": round(1 / 4.0, 3), "dependent_chains_8_waves": round(1 / 2.95, 3),
+                                                 "frac_of_8_wave_rate": round(per_cycle * 2.95, 3),
+                                                 "note": "branches, waits and scalar memory instructions are not in the counted kinds (+ ~12 %)"}
         if not decode and not a.no_extras and not a.serial_calls:
             # the same steps without the input-ready promise: every call waits for the previous one to drain
             batch.set_input_ready(False)
