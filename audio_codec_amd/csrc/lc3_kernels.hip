@@ -546,9 +546,13 @@ template <class LdsT> STAGE void st_olpa(const lc3d_plan* __restrict__ P, LdsT& 
     float* R0 = &L.sm[L.MISC];                     /* 98 unweighted autocorrelations */
     const bool two = lane < 34;
     const float* q0 = s6 - (17 + lane); const float* q1 = s6 - (two ? 81 + lane : 17 + lane);
-    float r0 = 0, r1 = 0;
+    /* the two ordered sums of a lane advance together in packed fp32 (v_pk_mul_f32 / v_pk_add_f32: two IEEE operations per instruction,
+     * each rounded like the scalar one) */
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 rr = {0.0f, 0.0f};
 #pragma unroll 8
-    for (int j = 0; j < acf; j++) { const float a = s6[j]; r0 += a * q0[j]; r1 += a * q1[j]; }
+    for (int j = 0; j < acf; j++) { const float a = s6[j]; const f32x2 av = {a, a}, qv = {q0[j], q1[j]}; rr = rr + av * qv; }
+    const float r0 = rr.x, r1 = rr.y;
     R0[lane] = r0;
     if (two) R0[64 + lane] = r1;
     float best = r0 * lc3t_olpa_w[lane]; int besti = lane;
