@@ -2911,6 +2911,15 @@ extern "C" int lc3hip_upload_chans(void* ctx, const lc3d_chan* chans, int first,
 /* the kernels of one call (or of one run of frames of a call) on stream s, PCM and output in device memory.  n_frames frames from
  * dpcm [stream][n_frames][channel][N]; the hand-over records and status bytes are rows of dT frames per channel-stream in which this
  * launch fills frames dt0 ... dt0 + n_frames - 1; with `pack` the bitstream writer then runs over all dT frames into dout [stream][dT][out_stride]. */
+#ifdef LC3_DUP
+/* diagnostic build (tools/variants.sh dup "-DLC3_DUP", tools/dup_run.sh): LC3PLUS_ENC_DUP=<letters> launches the named kernels of the pipelined
+ * path twice (r resampler, h HP50, p pitch, f front, v quantiser, s rate, k pack) - what a kernel costs in the co-resident mix.  Output is
+ * wrong for the kernels that carry state (h, p, s); never built into the product library. */
+static int dup_of(char k) { static const char* e = nullptr; static bool rd = false; if (!rd) { e = getenv("LC3PLUS_ENC_DUP"); rd = true; } return e && strchr(e, k) ? 2 : 1; }
+#define DUPL(k) for (int dup_ = 0; dup_ < dup_of(k); dup_++)
+#else
+#define DUPL(k)
+#endif
 static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frames, uint8_t* dout, int out_stride, hipStream_t s, lc3d_trace* dtr,
                       int dT, int dt0, bool pack)
 {
@@ -3006,27 +3015,27 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
             if (tb >= hb) {
                 const int hn0 = hk == 0 ? Tr : 4 * Tr, hn = n_frames - hb < hn0 ? n_frames - hb : hn0;
                 const unsigned pruns = (unsigned)((hn + PRE_FPW - 1) / PRE_FPW);
-                hipLaunchKernelGGL(lc3_enc_resample_kernel, dim3((unsigned)c->ncs * pruns), dim3(WAVE), 0, c->s_pre, c->d_plan, c->d_state, c->state_words, mc, dpcm, bitdepth, n_frames, hb, hn, c->ncs, dy12, xprev, xprev_stride);
-                hipLaunchKernelGGL(lc3_enc_hp50_kernel, dim3((unsigned)((c->ncs + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->s_pre, c->d_plan, c->d_state, c->state_words, LC3D_ST_SCAL(mc), n_frames, hb, hn, c->ncs, dy12);
+                DUPL('r') hipLaunchKernelGGL(lc3_enc_resample_kernel, dim3((unsigned)c->ncs * pruns), dim3(WAVE), 0, c->s_pre, c->d_plan, c->d_state, c->state_words, mc, dpcm, bitdepth, n_frames, hb, hn, c->ncs, dy12, xprev, xprev_stride);
+                DUPL('h') hipLaunchKernelGGL(lc3_enc_hp50_kernel, dim3((unsigned)((c->ncs + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->s_pre, c->d_plan, c->d_state, c->state_words, LC3D_ST_SCAL(mc), n_frames, hb, hn, c->ncs, dy12);
                 HIPCHK(hipGetLastError());
                 hb += hn; hk++;
             }
-            hipLaunchKernelGGL(lc3_enc_pitch_kernel, dim3(c->ncs), dim3(WAVE), 0, c->s_pre, c->d_plan, c->d_chans, c->d_state, c->state_words, mc, dy12, n_frames, tb, nt, c->ncs, dfrec);
+            DUPL('p') hipLaunchKernelGGL(lc3_enc_pitch_kernel, dim3(c->ncs), dim3(WAVE), 0, c->s_pre, c->d_plan, c->d_chans, c->d_state, c->state_words, mc, dy12, n_frames, tb, nt, c->ncs, dfrec);
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(c->ev_p[k], c->s_pre));
             const int fpw = nt < FRONT_FPW ? nt : FRONT_FPW;
             const unsigned fruns = (unsigned)((nt + fpw - 1) / fpw);
             if (c->big) hipLaunchKernelGGL(lc3_enc_front_kernel_big, dim3((unsigned)c->ncs * fruns), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames, tb, nt, fpw, c->ncs, dspec, dfrec, xn_w, xprev, xprev_stride);
-            else hipLaunchKernelGGL(lc3_enc_front_kernel, dim3((unsigned)c->ncs * fruns), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames, tb, nt, fpw, c->ncs, dspec, dfrec, xn_w, xprev, xprev_stride);
+            else DUPL('f') hipLaunchKernelGGL(lc3_enc_front_kernel, dim3((unsigned)c->ncs * fruns), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames, tb, nt, fpw, c->ncs, dspec, dfrec, xn_w, xprev, xprev_stride);
             if (c->any_attack)
                 hipLaunchKernelGGL(lc3_enc_attack_kernel, dim3((unsigned)((c->ncs + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, c->state_words, LC3D_ST_SCAL(mc), dfrec, n_frames, tb, nt, c->ncs);
             const long long nfr = (long long)c->ncs * nt;
-            hipLaunchKernelGGL(lc3_enc_snsvq_kernel, dim3((unsigned)((nfr + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->s_fr, c->d_plan, dfrec, n_frames, tb, nt, c->ncs, c->any_attack);
+            DUPL('v') hipLaunchKernelGGL(lc3_enc_snsvq_kernel, dim3((unsigned)((nfr + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->s_fr, c->d_plan, dfrec, n_frames, tb, nt, c->ncs, c->any_attack);
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(c->ev_f[k], c->s_fr));
             HIPCHK(hipStreamWaitEvent(s, c->ev_p[k], 0)); HIPCHK(hipStreamWaitEvent(s, c->ev_f[k], 0));
             if (c->big) hipLaunchKernelGGL(lc3_enc_seq_kernel_big, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, n_frames, tb, nt, c->ncs, ddump, dstride, dT, dt0, c->d_status, dspec, dfrec, xn_w);
-            else hipLaunchKernelGGL(lc3_enc_seq_kernel, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, n_frames, tb, nt, c->ncs, ddump, dstride, dT, dt0, c->d_status, dspec, dfrec, xn_w);
+            else DUPL('s') hipLaunchKernelGGL(lc3_enc_seq_kernel, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, n_frames, tb, nt, c->ncs, ddump, dstride, dT, dt0, c->d_status, dspec, dfrec, xn_w);
             HIPCHK(hipGetLastError());
             if (c->input_ready && R <= LC3D_AHEAD_MAX_RUNS) HIPCHK(hipEventRecord(c->ev_s[k], s));
         }
@@ -3037,7 +3046,7 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
         const int wpg = 4;
         const size_t per_wave = (size_t)PK_XBUF * WAVE * sizeof(unsigned);
         const long long tasks = (long long)c->ncs * dT, per_wg = (long long)wpg * WAVE;
-        hipLaunchKernelGGL(lc3_enc_pack_kernel, dim3((unsigned)((tasks + per_wg - 1) / per_wg)), dim3(wpg * WAVE), per_wave * wpg, s, c->d_plan, c->d_chans, ddump, dstride,
+        DUPL('k') hipLaunchKernelGGL(lc3_enc_pack_kernel, dim3((unsigned)((tasks + per_wg - 1) / per_wg)), dim3(wpg * WAVE), per_wave * wpg, s, c->d_plan, c->d_chans, ddump, dstride,
                            dT, 0, dT, c->ncs, dout, out_stride, c->d_status);
     }
     HIPCHK(hipGetLastError());
