@@ -1664,6 +1664,7 @@ template <class LdsT> STAGE int tns_quant(LdsT& L, int lane, int nf, int maxOrde
  * consecutive bins and first replays the 8 preceding inputs; bins before the filter start come from the carried state. */
 template <class LdsT> STAGE void tns_lattice(LdsT& L, int lane, int f, int b_first, int cnt, int ord)
 {
+    f = uni(f); b_first = uni(b_first); cnt = uni(cnt); ord = uni(ord);
     float* stt = &L.sm[SM_MISC + 96];
     const float* rcs = TNS_RCS(L, f);
     float* X = XCUR(L);
@@ -1940,6 +1941,7 @@ template <class LdsT> STAGE void st_gain_estimate(const lc3d_plan* __restrict__ 
 /* ---- quantisation + exact bit estimate R/quantize_spec.c:26-197 ---- */
 template <class LdsT> STAGE void st_quantize(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ C, LdsT& L, int lane, int mode, int target)
 {
+    mode = uni(mode); target = uni(target);       /* arguments arrive in vector registers: wave-uniform ones go to scalar registers, or every test of them is a masked region */
     const int nt = PI(ylen), fs = PI(fs), tb = CI(total_bits);
     const float offs = PI(hrmode) ? 0.5f : 0.375f;
     const float gain = unif(L.fsc[F_GAIN]);
@@ -2087,6 +2089,7 @@ template <class LdsT> __device__ __forceinline__ void gain_adjust(const lc3d_pla
  * the serial float sums fed from lane registers with readlane (no list in LDS). */
 template <class LdsT> STAGE void st_noise_factor(const lc3d_plan* __restrict__ P, LdsT& L, int lane, int bw_bin)
 {
+    bw_bin = uni(bw_bin);
     const int dms = PI(dms);
     const int width = dms == 100 ? 8 : 4, first = dms == 100 ? 24 : dms == 50 ? 12 : 6, hw = (width - 2) / 2;
     const float gg = unif(L.fsc[F_GAIN]);
