@@ -106,6 +106,8 @@ def test_batch_argument_validation(lib):
     assert f(C.byref(h), 2, 96000, 1, 10.0, 0, br, -1) == 6      # 96 kHz forces hrmode (R/setup_enc_lc3.c:93-96); 64 kbps is below the hrmode minimum
     bad = (C.c_int * 2)(64000, 1000)
     assert f(C.byref(h), 2, 48000, 1, 10.0, 0, bad, -1) in (1, 6)   # bitrate error (6) unless no device was found first (1)
+    lib.lc3plus_enc_batch_set_input_ready.argtypes = [C.c_void_p, C.c_int]
+    assert lib.lc3plus_enc_batch_set_input_ready(None, 1) == 3 and lib.lc3plus_enc_batch_last_status(None, None, 0) == -1
 
 
 def test_decoder_configuration_matches_reference_derivation(lib):
