@@ -2830,8 +2830,8 @@ extern "C" __global__ void lc3_enc_seq_kernel_big(const lc3d_plan* __restrict__ 
 #include "lc3_enc_snsvq.inc"
 #include "lc3_enc_pre.inc"
 #define LC3D_MAX_RUNS 16
-#define LC3D_AHEAD_MAX_RUNS 6         /* lc3hip_set_input_ready: calls of up to this many runs overlap with their predecessor */
-#define LC3D_RUN_FRAMES 4
+#define LC3D_AHEAD_MAX_FRAMES 40      /* lc3hip_set_input_ready: calls of up to this many frames overlap with their predecessor */
+#define LC3D_RUN_FRAMES 8
 struct lc3hip_ctx {
     int device, ncs, n_streams, channels, N, big, state_words;
     lc3d_plan* d_plan; lc3d_chan* d_chans; float* d_state;
@@ -2987,7 +2987,9 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
             for (int i = 0; i < LC3D_MAX_RUNS; i++) { HIPCHK(hipEventCreateWithFlags(&c->ev_p[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_f[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_s[i], hipEventDisableTiming)); }
         }
         float* dspec = c->d_spec; float* dfrec = c->d_frec;
-        int R = (n_frames + LC3D_RUN_FRAMES - 1) / LC3D_RUN_FRAMES;              /* runs of LC3D_RUN_FRAMES frames */
+        static int runf = 0;
+        if (!runf) { const char* e = getenv("LC3PLUS_ENC_RUN_FRAMES"); runf = e && atoi(e) >= 1 ? atoi(e) : LC3D_RUN_FRAMES; }     /* diagnostic */
+        int R = (n_frames + runf - 1) / runf;              /* runs of LC3D_RUN_FRAMES frames */
         if (R > LC3D_MAX_RUNS) R = LC3D_MAX_RUNS;
         if (R < 1) R = 1;
         { const char* e = getenv("LC3PLUS_ENC_RUNS"); if (e && atoi(e) >= 1 && atoi(e) <= LC3D_MAX_RUNS) R = atoi(e); }     /* diagnostic */
@@ -3000,8 +3002,10 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
          * buffers), not from the state that call's last rate kernel is still to update. */
         /* Measured (bench.py --frames F with / without --serial-calls, Mframes/s): 12 frames 55.9 / 47.2, 16: 56.7 / 51.4, 24: 60.6 / 58.5,
          * 32: 61.8 / 61.8, 64: 64.6 / 68.2 - a long call loses more to the bitstream writer sharing the chip with the next call's side
-         * kernels than it gains at its ends, so the overlap is taken for calls of up to LC3D_AHEAD_MAX_RUNS runs. */
-        const bool ahead = c->input_ready && R <= LC3D_AHEAD_MAX_RUNS && c->ahead_ok && c->ahead_T == n_frames && c->ahead_R == R && c->last_stream == s && dt0 == 0 && dT == n_frames && pack;
+         * kernels than it gains at its ends, so the overlap is taken for calls of up to LC3D_AHEAD_MAX_FRAMES frames. */
+        static int amax = 0;
+        if (!amax) { const char* e = getenv("LC3PLUS_ENC_AHEAD_MAX"); amax = e && atoi(e) >= 1 ? atoi(e) : LC3D_AHEAD_MAX_FRAMES; }     /* diagnostic */
+        const bool ahead = c->input_ready && n_frames <= amax && c->ahead_ok && c->ahead_T == n_frames && c->ahead_R == R && c->last_stream == s && dt0 == 0 && dT == n_frames && pack;
         float* xn_w = c->d_xnext[c->xn_par];                         /* written by this call's front kernel */
         const float* xprev = ahead ? c->d_xnext[c->xn_par ^ 1] : c->d_state + LC3D_ST_XPREV;
         const int xprev_stride = ahead ? mc : c->state_words;
@@ -3016,7 +3020,9 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
             const int nt = n_frames - tb < Tr ? n_frames - tb : Tr;
             if (ahead) { HIPCHK(hipStreamWaitEvent(c->s_pre, c->ev_s[k], 0)); HIPCHK(hipStreamWaitEvent(c->s_fr, c->ev_s[k], 0)); }
             if (tb >= hb) {
-                const int hn0 = hk == 0 ? Tr : 4 * Tr, hn = n_frames - hb < hn0 ? n_frames - hb : hn0;
+                static int prn = 0;
+                if (!prn) { const char* e = getenv("LC3PLUS_ENC_PRE_RUNS"); prn = e && atoi(e) >= 1 ? atoi(e) : 3; }     /* diagnostic */
+                const int hn0 = hk == 0 ? Tr : prn * Tr, hn = n_frames - hb < hn0 ? n_frames - hb : hn0;
                 const unsigned pruns = (unsigned)((hn + PRE_FPW - 1) / PRE_FPW);
                 DUPL('r') hipLaunchKernelGGL(lc3_enc_resample_kernel, dim3((unsigned)c->ncs * pruns), dim3(WAVE), 0, c->s_pre, c->d_plan, c->d_state, c->state_words, mc, dpcm, bitdepth, n_frames, hb, hn, c->ncs, dy12, xprev, xprev_stride);
                 DUPL('h') hipLaunchKernelGGL(lc3_enc_hp50_kernel, dim3((unsigned)((c->ncs + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->s_pre, c->d_plan, c->d_state, c->state_words, LC3D_ST_SCAL(mc), n_frames, hb, hn, c->ncs, dy12);
@@ -3040,7 +3046,7 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
             if (c->big) hipLaunchKernelGGL(lc3_enc_seq_kernel_big, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, n_frames, tb, nt, c->ncs, ddump, dstride, dT, dt0, c->d_status, dspec, dfrec, xn_w);
             else DUPL('s') hipLaunchKernelGGL(lc3_enc_seq_kernel, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, n_frames, tb, nt, c->ncs, ddump, dstride, dT, dt0, c->d_status, dspec, dfrec, xn_w);
             HIPCHK(hipGetLastError());
-            if (c->input_ready && R <= LC3D_AHEAD_MAX_RUNS) HIPCHK(hipEventRecord(c->ev_s[k], s));
+            if (c->input_ready && n_frames <= amax) HIPCHK(hipEventRecord(c->ev_s[k], s));
         }
         c->ahead_ok = (dt0 == 0 && dT == n_frames && pack) ? 1 : 0; c->ahead_T = n_frames; c->ahead_R = R; c->xn_par ^= 1;
     }
