@@ -2849,7 +2849,7 @@ struct lc3hip_ctx {
 };
 
 #define LC3D_FUSED_MAX_T 8
-#define LC3D_FUSED_MAX_T_READY 4
+#define LC3D_FUSED_MAX_T_READY 3
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "lc3plus_hip: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); return 1; } } while (0)
 /* inside the create functions: release what has been allocated so far (the caller only sees ctx == NULL) */
 #define HIPCHK_OR(x, cleanup) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "lc3plus_hip: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); cleanup; return 1; } } while (0)
@@ -2933,8 +2933,9 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
      * 80 bytes whatever the batch size): up to LC3D_FUSED_MAX_T frames per call the wave-parallel writer inside the first kernel
      * (st_bitstream, ~6 us per frame) is used instead - the single-stream lc3_enc_* API and T = 1 batches live here. */
     int* ddump = nullptr; int dstride = 0;
-    /* with the input-ready promise consecutive short calls overlap on the pipelined path, which then wins from 5 frames per call
-     * (4096 streams, Mframes/s pipelined / in-kernel writer: 4 frames 39.5 / 37.9, 6: 43.8 / 40.2, 8: 52 / 41.2; without the promise 8: 40.2 / 41.2) */
+    /* with the input-ready promise consecutive short calls overlap on the pipelined path, which then wins from 4 frames per call
+     * (4096 streams, Mframes/s pipelined / in-kernel writer: 3 frames 31.9 / 36.3, 4: 39.8 / 38.0, 6: 48.6 / 40.2, 8: 53.9 / 41.2; without the
+     * promise 8: 40.2 / 41.2) */
     const bool in_kernel_writer = dtr || c->fused || dT <= (c->input_ready ? LC3D_FUSED_MAX_T_READY : LC3D_FUSED_MAX_T);
     if (!in_kernel_writer) {
         dstride = PK_STRIDE(c->N, c->hr);
