@@ -537,8 +537,10 @@ class _Dev:
     (16000, 5.0, 0, 80, 256, 20, 4, [32000, 64000]),
     (96000, 10.0, 1, 960, 64, 12, 4, [256000, 400000]),                               # the large-layout kernels
     (48000, 2.5, 0, 120, 256, 24, 4, [128000, 64000]),
-    (48000, 10.0, 0, 480, 512, 6, 6, [64000, 128000]),                                # short calls: pipelined from 5 frames under the promise
+    (48000, 10.0, 0, 480, 512, 6, 6, [64000, 128000]),                                # short calls: pipelined from 4 frames under the promise
     (48000, 10.0, 0, 480, 512, 5, 4, [64000]),
+    (48000, 10.0, 0, 480, 256, 4, 5, [64000, 96000]),
+    (48000, 10.0, 0, 480, 256, 40, 3, [64000]),                                       # the longest calls that overlap: five runs of 8 frames
 ])
 def test_consecutive_calls_overlap_with_input_ready(fs, ms, hr, N, B, T, K, rates):
     """lc3plus_enc_batch_set_input_ready: K device-pointer calls queued back to back without a host synchronisation in between - the side
