@@ -237,7 +237,7 @@ def main():
         prof = committed_profile(a.workload, B, T)
         kernels = ("lc3_dec_parse_kernel + lc3_dec_plc_kernel + lc3_dec_imdct_kernel + lc3_dec_synth_kernel" if decode else
                    "lc3_enc_resample/hp50/pitch_kernel (pitch chain) || lc3_enc_front/attack/snsvq_kernel (frame-parallel front) -> lc3_enc_seq_kernel (rate chain), "
-                   "16 runs of 4 frames on three HIP streams, then lc3_enc_pack_kernel")
+                   "runs of 8 frames on three HIP streams, then lc3_enc_pack_kernel")
         res = {
             "metric": "Mframes/s encoded (48kHz/10ms/64kbps)" if a.workload == "c1" else "Mframes/s %s (channel-frames)" % ("decoded" if decode else "encoded"),
             "value": round(value, 4), "unit": "Mframes/s",
