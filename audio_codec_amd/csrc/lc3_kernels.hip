@@ -157,9 +157,12 @@ __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlan
  * (SURVEY 9): 2^21-1, 2^22-{1,2}, 2^23-{1..5}, 2^24-{1..11}. */
 __device__ __forceinline__ int flog2f_int(unsigned v)
 {
-    int e = ilog2(v), b = e + 1;
-    unsigned k = (1u << b) - v;
-    if ((b == 21 && k <= 1) || (b == 22 && k <= 2) || (b == 23 && k <= 5) || (b == 24 && k <= 11)) return b;
+    int e = ilog2(v);
+    if (v >= (1u << 20)) {                          /* the only values the rounding can lift; a masked region the wave skips otherwise */
+        const int b = e + 1;
+        const unsigned k = (1u << b) - v;
+        if ((b == 21 && k <= 1) || (b == 22 && k <= 2) || (b == 23 && k <= 5) || (b == 24 && k <= 11)) e = b;
+    }
     return e;
 }
 
