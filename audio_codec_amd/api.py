@@ -18,7 +18,8 @@ EXPORTS = [
     "lc3_enc_fl", "lc3_enc16", "lc3_enc24", "lc3_enc32", "lc3_enc_free_memory", "lc3_free_encoder_structs",
     "lc3plus_enc_batch_create", "lc3plus_enc_batch_destroy", "lc3plus_enc_batch_input_samples",
     "lc3plus_enc_batch_num_bytes", "lc3plus_enc_batch_stride", "lc3plus_enc_batch_set_bitrate",
-    "lc3plus_enc_batch_set_bandwidth", "lc3plus_enc_batch_encode", "lc3plus_enc_batch_last_kernel_ms", "lc3plus_enc_batch_last_status", "lc3plus_enc_batch_set_input_ready",
+    "lc3plus_enc_batch_set_bandwidth", "lc3plus_enc_batch_encode", "lc3plus_enc_batch_last_kernel_ms", "lc3plus_enc_batch_last_status", "lc3plus_enc_batch_set_input_ready", "lc3plus_enc_batch_state_size", "lc3plus_enc_batch_get_state", "lc3plus_enc_batch_set_state",
+    "lc3plus_dec_batch_state_size", "lc3plus_dec_batch_get_state", "lc3plus_dec_batch_set_state",
     "lc3plus_enc_init", "lc3plus_enc_set_frame_ms", "lc3plus_enc_set_hrmode", "lc3plus_enc_set_bitrate",
     "lc3plus_enc16", "lc3plus_enc_get_size",
     "lc3_dec_get_size", "lc3_dec_init", "lc3_dec_set_frame_ms", "lc3_dec_set_hrmode", "lc3_dec_get_output_samples",
@@ -59,6 +60,10 @@ def load_library():
         L.lc3plus_enc_batch_last_kernel_ms.argtypes = [C.c_void_p]
         L.lc3plus_enc_batch_last_status.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.lc3plus_enc_batch_set_input_ready.argtypes = [C.c_void_p, C.c_int]
+        for nm in ("lc3plus_enc_batch", "lc3plus_dec_batch"):
+            getattr(L, nm + "_state_size").argtypes = [C.c_void_p]; getattr(L, nm + "_state_size").restype = C.c_size_t
+            getattr(L, nm + "_get_state").argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+            getattr(L, nm + "_set_state").argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         for f in ("lc3plus_enc_batch_destroy", "lc3plus_enc_batch_input_samples", "lc3plus_enc_batch_stride"):
             getattr(L, f).argtypes = [C.c_void_p]
         L.lc3plus_enc_batch_num_bytes.argtypes = [C.c_void_p, C.c_int]
@@ -140,6 +145,20 @@ class Batch:
         rc = self.lib.lc3plus_enc_batch_set_input_ready(self.h, 1 if ready else 0)
         if rc:
             raise LC3Error(rc, "lc3plus_enc_batch_set_input_ready")
+
+    def get_state(self):
+        """The cross-frame state of all streams (opaque bytes): checkpoint for set_state() on a batch of the same configuration."""
+        st = np.zeros(self.lib.lc3plus_enc_batch_state_size(self.h), dtype=np.uint8)
+        rc = self.lib.lc3plus_enc_batch_get_state(self.h, st.ctypes.data, st.size)
+        if rc:
+            raise LC3Error(rc, "lc3plus_enc_batch_get_state")
+        return st
+
+    def set_state(self, st):
+        st = np.ascontiguousarray(st, dtype=np.uint8)
+        rc = self.lib.lc3plus_enc_batch_set_state(self.h, st.ctypes.data, st.size)
+        if rc:
+            raise LC3Error(rc, "lc3plus_enc_batch_set_state")
 
     def last_status(self, T):
         """uint8 [n_streams * channels, T]: LC3D_ENC_ST_* bits of the last call (0 = nothing the reference would assert on)."""
@@ -241,6 +260,20 @@ class DecBatch:
 
     def set_num_bytes(self, stream, nbytes):
         return self.lib.lc3plus_dec_batch_set_num_bytes(self.h, stream, nbytes)
+
+    def get_state(self):
+        """The decoders' cross-frame state (opaque bytes): checkpoint for set_state() on a batch of the same configuration."""
+        st = np.zeros(self.lib.lc3plus_dec_batch_state_size(self.h), dtype=np.uint8)
+        rc = self.lib.lc3plus_dec_batch_get_state(self.h, st.ctypes.data, st.size)
+        if rc:
+            raise LC3Error(rc, "lc3plus_dec_batch_get_state")
+        return st
+
+    def set_state(self, st):
+        st = np.ascontiguousarray(st, dtype=np.uint8)
+        rc = self.lib.lc3plus_dec_batch_set_state(self.h, st.ctypes.data, st.size)
+        if rc:
+            raise LC3Error(rc, "lc3plus_dec_batch_set_state")
 
     def _prep(self, frames, bfi, bps):
         frames = np.ascontiguousarray(frames, dtype=np.uint8)

@@ -412,6 +412,18 @@ int lc3plus_enc_batch_last_status(lc3plus_batch* b, uint8_t* status, int max_ent
     return lc3hip_last_status(b->dev, status, max_entries);
 }
 
+size_t lc3plus_enc_batch_state_size(const lc3plus_batch* b) { return b ? lc3hip_state_bytes(b->dev) : 0; }
+LC3_Error lc3plus_enc_batch_get_state(lc3plus_batch* b, void* state, size_t size)
+{
+    if (!b || !state) return LC3_NULL_ERROR;
+    return lc3hip_get_state(b->dev, state, size) ? LC3_ERROR : LC3_OK;
+}
+LC3_Error lc3plus_enc_batch_set_state(lc3plus_batch* b, const void* state, size_t size)
+{
+    if (!b || !state) return LC3_NULL_ERROR;
+    return lc3hip_set_state(b->dev, state, size) ? LC3_ERROR : LC3_OK;
+}
+
 LC3_Error lc3plus_enc_batch_set_input_ready(lc3plus_batch* b, int ready)
 {
     if (!b) return LC3_NULL_ERROR;
@@ -686,6 +698,18 @@ LC3_Error lc3plus_dec_batch_create(lc3plus_dec_batch** out, int n_streams, int s
     if (rc) { if (b->dev) lc3hip_dec_destroy(b->dev); free(b->chans); free(b); return LC3_ERROR; }
     *out = b;
     return LC3_OK;
+}
+
+size_t lc3plus_dec_batch_state_size(const lc3plus_dec_batch* b) { return b ? lc3hip_dec_state_bytes(b->dev) : 0; }
+LC3_Error lc3plus_dec_batch_get_state(lc3plus_dec_batch* b, void* state, size_t size)
+{
+    if (!b || !state) return LC3_NULL_ERROR;
+    return lc3hip_dec_get_state(b->dev, state, size) ? LC3_ERROR : LC3_OK;
+}
+LC3_Error lc3plus_dec_batch_set_state(lc3plus_dec_batch* b, const void* state, size_t size)
+{
+    if (!b || !state) return LC3_NULL_ERROR;
+    return lc3hip_dec_set_state(b->dev, state, size) ? LC3_ERROR : LC3_OK;
 }
 
 LC3_Error lc3plus_dec_batch_destroy(lc3plus_dec_batch* b)

@@ -3179,6 +3179,29 @@ extern "C" int lc3hip_last_status(void* ctx, uint8_t* status_host, int n)
     return n;
 }
 
+/* checkpoint / resume: the cross-frame state of every channel-stream (LC3D_STATE_WORDS words each, the layout of lc3_plan.h) as one host
+ * array; everything else a batch holds is derived from its configuration.  Both wait for the last call to finish. */
+extern "C" size_t lc3hip_state_bytes(void* ctx) { lc3hip_ctx* c = (lc3hip_ctx*)ctx; return c ? sizeof(float) * (size_t)c->state_words * (size_t)c->ncs : 0; }
+extern "C" int lc3hip_get_state(void* ctx, void* host, size_t bytes)
+{
+    lc3hip_ctx* c = (lc3hip_ctx*)ctx;
+    if (!c || !host || bytes != lc3hip_state_bytes(ctx)) return 1;
+    HIPCHK(hipSetDevice(c->device));
+    if (c->last_stream) HIPCHK(hipStreamSynchronize(c->last_stream));
+    HIPCHK(hipMemcpy(host, c->d_state, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+extern "C" int lc3hip_set_state(void* ctx, const void* host, size_t bytes)
+{
+    lc3hip_ctx* c = (lc3hip_ctx*)ctx;
+    if (!c || !host || bytes != lc3hip_state_bytes(ctx)) return 1;
+    HIPCHK(hipSetDevice(c->device));
+    if (c->last_stream) HIPCHK(hipStreamSynchronize(c->last_stream));
+    HIPCHK(hipMemcpy(c->d_state, host, bytes, hipMemcpyHostToDevice));
+    c->ahead_ok = 0;                       /* the MDCT memory is in the state, not in a previous call's hand-over */
+    return 0;
+}
+
 extern "C" int lc3hip_set_input_ready(void* ctx, int ready)
 {
     lc3hip_ctx* c = (lc3hip_ctx*)ctx;
@@ -3374,6 +3397,25 @@ extern "C" int lc3hip_dec_decode(void* ctx, const void* frames, int frames_on_de
         HIPCHK(hipStreamSynchronize(s));
         float ms = 0; if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->last_ms = ms;
     }
+    return 0;
+}
+extern "C" size_t lc3hip_dec_state_bytes(void* ctx) { lc3hip_dctx* c = (lc3hip_dctx*)ctx; return c ? sizeof(float) * (size_t)DST_WORDS * (size_t)c->ncs : 0; }
+extern "C" int lc3hip_dec_get_state(void* ctx, void* host, size_t bytes)
+{
+    lc3hip_dctx* c = (lc3hip_dctx*)ctx;
+    if (!c || !host || bytes != lc3hip_dec_state_bytes(ctx)) return 1;
+    HIPCHK(hipSetDevice(c->device));
+    if (c->last_stream) HIPCHK(hipStreamSynchronize(c->last_stream));
+    HIPCHK(hipMemcpy(host, c->d_state, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+extern "C" int lc3hip_dec_set_state(void* ctx, const void* host, size_t bytes)
+{
+    lc3hip_dctx* c = (lc3hip_dctx*)ctx;
+    if (!c || !host || bytes != lc3hip_dec_state_bytes(ctx)) return 1;
+    HIPCHK(hipSetDevice(c->device));
+    if (c->last_stream) HIPCHK(hipStreamSynchronize(c->last_stream));
+    HIPCHK(hipMemcpy(c->d_state, host, bytes, hipMemcpyHostToDevice));
     return 0;
 }
 extern "C" float lc3hip_dec_last_ms(void* ctx) { return ctx ? ((lc3hip_dctx*)ctx)->last_ms : 0.0f; }

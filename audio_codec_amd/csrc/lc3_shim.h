@@ -2,6 +2,7 @@
 #ifndef LC3_SHIM_H
 #define LC3_SHIM_H
 #include <stdint.h>
+#include <stddef.h>
 #include "lc3_plan.h"
 
 /* per channel-frame intermediates (debug / stage-level parity tests); same field order as oracle/lc3_oracle.h:lc3o_trace */
@@ -35,6 +36,12 @@ int   lc3hip_upload_chans(void* ctx, const lc3d_chan* chans, int first, int coun
 int   lc3hip_encode(void* ctx, const void* pcm, int pcm_on_device, int bitdepth, int n_frames, void* out, int out_stride,
                     int out_on_device, void* hip_stream, int sync, void* trace_host);
 float lc3hip_last_ms(void* ctx);
+size_t lc3hip_state_bytes(void* ctx);                             /* checkpoint / resume of the per-stream state (include/lc3plus_batch.h) */
+int   lc3hip_get_state(void* ctx, void* host, size_t bytes);
+int   lc3hip_set_state(void* ctx, const void* host, size_t bytes);
+size_t lc3hip_dec_state_bytes(void* ctx);
+int   lc3hip_dec_get_state(void* ctx, void* host, size_t bytes);
+int   lc3hip_dec_set_state(void* ctx, const void* host, size_t bytes);
 int   lc3hip_set_input_ready(void* ctx, int ready);              /* see lc3plus_enc_batch_set_input_ready (include/lc3plus_batch.h) */
 int   lc3hip_last_status(void* ctx, uint8_t* status_host, int n);   /* LC3D_ENC_ST_* bits per channel-frame of the last call; returns the count copied */
 int   lc3hip_destroy(void* ctx);

@@ -11,6 +11,7 @@
 #ifndef LC3PLUS_BATCH_H
 #define LC3PLUS_BATCH_H
 #include "lc3.h"
+#include <stddef.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -41,6 +42,14 @@ LC3_Error lc3plus_enc_batch_set_bandwidth(lc3plus_batch* batch, int stream, int 
 LC3_Error lc3plus_enc_batch_encode(lc3plus_batch* batch, const void* pcm, int pcm_on_device, int bitdepth,
                                    int n_frames, void* out, int out_stride, int out_on_device,
                                    void* hip_stream, int sync);
+
+/* Checkpoint / resume.  The cross-frame state of every channel-stream of the batch (MDCT / resampler memory, pitch and LTPF histories,
+ * rate-control and attack-detector words; R/setup_enc_lc3.h:17-62) as one opaque host array of state_size() bytes.  A batch created with
+ * the same (n_streams, samplerate, channels, frame_ms, hrmode, bitrates, bandwidths) that is given the state continues the streams
+ * exactly where the first one stopped - on another GPU or in another process.  Both calls wait for the last encode() to finish. */
+size_t    lc3plus_enc_batch_state_size(const lc3plus_batch* batch);
+LC3_Error lc3plus_enc_batch_get_state(lc3plus_batch* batch, void* state, size_t size);
+LC3_Error lc3plus_enc_batch_set_state(lc3plus_batch* batch, const void* state, size_t size);
 
 /* A promise about device-pointer calls, off by default: with ready != 0 the caller guarantees that the PCM passed to every following
  * encode() call is COMPLETE in device memory when the call is made - not merely queued earlier on hip_stream (so it is wrong for PCM
@@ -78,6 +87,11 @@ LC3_Error lc3plus_dec_batch_decode(lc3plus_dec_batch* batch, const void* frames,
                                    const uint8_t* bfi, int n_frames, void* pcm, int pcm_on_device, int bps,
                                    uint8_t* status, void* hip_stream, int sync);
 float     lc3plus_dec_batch_last_kernel_ms(lc3plus_dec_batch* batch);
+/* checkpoint / resume of the decoders' cross-frame state (overlap-add memory, last good spectrum, LTPF histories, concealment words), as
+ * for the encoder batch; the frame sizes are configuration (lc3plus_dec_batch_set_num_bytes), not state */
+size_t    lc3plus_dec_batch_state_size(const lc3plus_dec_batch* batch);
+LC3_Error lc3plus_dec_batch_get_state(lc3plus_dec_batch* batch, void* state, size_t size);
+LC3_Error lc3plus_dec_batch_set_state(lc3plus_dec_batch* batch, const void* state, size_t size);
 
 /* lc3plus_enc_* spellings of the single-stream API (north-star wording); thin aliases. */
 LC3_Error lc3plus_enc_init(LC3_Enc* e, int samplerate, int channels);

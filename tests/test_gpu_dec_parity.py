@@ -126,6 +126,26 @@ def test_long_loss_bursts():
     assert (got == want).all()
 
 
+def test_checkpoint_resume_state():
+    """lc3plus_dec_batch_get_state / set_state: a second batch of the same configuration given the first one's state continues the
+    streams sample for sample - the checkpoint taken in the middle of a loss burst (concealment counters, attenuation, last good
+    spectrum, overlap memory and LTPF histories all cross it)."""
+    rates = [32000, 64000, 96000, 160000]
+    frames, nbytes, _ = make_dec_case(48000, 10.0, 0, 1, rates, 30, seed=77, loss=0.1, corrupt=0.05)
+    bfi = np.zeros((4, 30), dtype=np.uint8); bfi[1, 9:14] = 1; bfi[3, 11] = 1
+    amd = _amd()
+    a = amd.DecBatch(4, 48000, 1, 10.0, 0, nbytes, device=0)
+    g1, s1 = a.decode(frames[:, :12], bfi[:, :12])
+    st = a.get_state()
+    b = amd.DecBatch(4, 48000, 1, 10.0, 0, nbytes, device=0)
+    b.set_state(st)
+    g2, s2 = b.decode(frames[:, 12:], bfi[:, 12:])
+    want, wstatus = oracle_decode_streams(frames, nbytes, bfi, 48000, 10.0, 0, 1)
+    assert (np.concatenate([g1, g2], axis=1) == want).all() and (np.concatenate([s1, s2], axis=1) == wstatus).all()
+    with pytest.raises(Exception):
+        b.set_state(st[:-4])                                   # a state of another size is refused
+
+
 def test_single_stream_api_with_rate_switch_and_empty_frames():
     """lc3_dec_fl as R/codec_exe.c drives it: frame size changes mid-stream (R/dec_lc3_fl.c:149-155), num_bytes = 0 means lost."""
     amd = _amd()

@@ -504,6 +504,31 @@ def test_attack_detector_on_the_split_path():
             assert (g[0, k, :o.nbytes] == o.encode(pcm[3, t0 + k][None])).all(), (t0, k)
 
 
+def test_checkpoint_resume_state():
+    """lc3plus_enc_batch_get_state / set_state: a second batch of the same configuration given the first one's state continues the
+    streams byte for byte (MDCT / resampler memory, pitch and LTPF histories, rate-control and attack-detector words); mixed bitrates
+    with attack handling, the first part through the pipelined path, the rest through short calls."""
+    amd = _amd()
+    B, T = 96, 30
+    rates = [64000, 96000, 128000, 32000, 256000, 16000]
+    br = [rates[i % len(rates)] for i in range(B)]
+    pcm = synth_pcm(B, T, 480, 48000, seed=909)
+    a = amd.Batch(B, 48000, 1, 10.0, 0, br, device=0)
+    g1 = a.encode(pcm[:, :13])
+    st = a.get_state()
+    assert st.size == a.lib.lc3plus_enc_batch_state_size(a.h) and st.size > 0
+    b = amd.Batch(B, 48000, 1, 10.0, 0, br, device=0)
+    b.set_state(st)
+    g2 = np.concatenate([b.encode(pcm[:, 13:20]), b.encode(pcm[:, 20:])], axis=1)
+    want = _oracle_batch(pcm, 48000, 10.0, 0, br, a.stride)
+    got = np.concatenate([g1, g2], axis=1)
+    nb = [a.num_bytes(i) for i in range(B)]
+    bad = [(i, t) for i in range(B) for t in range(T) if (got[i, t, :nb[i]] != want[i, t, :nb[i]]).any()]
+    assert not bad, (len(bad), bad[:8])
+    with pytest.raises(Exception):
+        b.set_state(st[:-4])                                   # a state of another size is refused
+
+
 class _Dev:
     """Device buffers through ctypes (hipMalloc / hipMemcpy): the tests do not depend on torch."""
     def __init__(self):

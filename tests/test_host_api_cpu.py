@@ -108,6 +108,9 @@ def test_batch_argument_validation(lib):
     assert f(C.byref(h), 2, 48000, 1, 10.0, 0, bad, -1) in (1, 6)   # bitrate error (6) unless no device was found first (1)
     lib.lc3plus_enc_batch_set_input_ready.argtypes = [C.c_void_p, C.c_int]
     assert lib.lc3plus_enc_batch_set_input_ready(None, 1) == 3 and lib.lc3plus_enc_batch_last_status(None, None, 0) == -1
+    lib.lc3plus_enc_batch_state_size.restype = C.c_size_t; lib.lc3plus_dec_batch_state_size.restype = C.c_size_t
+    assert lib.lc3plus_enc_batch_state_size(None) == 0 and lib.lc3plus_dec_batch_state_size(None) == 0
+    assert lib.lc3plus_enc_batch_get_state(None, None, 0) == 3 and lib.lc3plus_dec_batch_set_state(None, None, 0) == 3
 
 
 def test_decoder_configuration_matches_reference_derivation(lib):
