@@ -126,6 +126,42 @@ def test_long_loss_bursts():
     assert (got == want).all()
 
 
+@pytest.mark.parametrize("fs,ms,hr,rates", [(48000, 10.0, 0, [64000, 128000]), (32000, 5.0, 0, [64000, 96000]), (96000, 2.5, 1, [256000, 400000])])
+def test_stage_traces_match_oracle(fs, ms, hr, rates):
+    """Stage by stage: what the traced entry point records per decoded channel-frame (side information, TNS orders and indices, scale
+    factor indices, LTPF parameters, noise-filling seed, zero-frame flag, residual count, the spectrum after TNS and after SNS shaping,
+    the IMDCT output and the synthesis output) equals the oracle decoder's trace exactly, on good frames of a stream with lost frames in
+    between (the fields the first kernel does not hand over are skipped, as in tests/gpu_dec_debug.py)."""
+    import ctypes as C
+    from lc3_harness import DecTrace, OracleDecoder
+    T = 10
+    frames, nbytes, bfi = make_dec_case(fs, ms, hr, 1, rates, T, seed=19, loss=0.2, corrupt=0)
+    B = len(rates)
+    N = int(fs * ms / 1000)
+    db = _amd().DecBatch(B, fs, 1, ms, hr, nbytes, device=0)
+    got, status, traces = db.decode_traced(frames, bfi)
+    bad = []
+    for b in range(B):
+        o = OracleDecoder(fs, 1, ms, hr, portable_math=True)
+        tr = o.enable_trace()
+        for t in range(T):
+            rc, want = o.decode(frames[b, t, :nbytes[b]], int(bfi[b, t]))
+            assert (got[b, t] == want).all() and int(status[b, t]) == int(rc == 2), (b, t)
+            if rc != 0: continue
+            g = DecTrace.from_buffer_copy(traces[b * T + t].tobytes()[:C.sizeof(DecTrace)])
+            for f, _ in DecTrace._fields_:
+                if f in ("bfi", "xq", "q_gain", "scf_q"): continue
+                ga, ca = getattr(g, f), getattr(tr[0], f)
+                if hasattr(ga, "__len__"):
+                    n = N if len(ga) == 960 else len(ga)
+                    a, c = np.ctypeslib.as_array(ga)[:n], np.ctypeslib.as_array(ca)[:n]
+                else:
+                    a, c = np.asarray([ga]), np.asarray([ca])
+                same = (a.view(np.uint32) == c.view(np.uint32)) | ((a == 0) & (c == 0)) if a.dtype.kind == "f" else (a == c)
+                if not same.all(): bad.append((b, t, f, int((~same).sum())))
+    assert not bad, bad[:10]
+
+
 def test_checkpoint_resume_state():
     """lc3plus_dec_batch_get_state / set_state: a second batch of the same configuration given the first one's state continues the
     streams sample for sample - the checkpoint taken in the middle of a loss burst (concealment counters, attenuation, last good

@@ -504,6 +504,42 @@ def test_attack_detector_on_the_split_path():
             assert (g[0, k, :o.nbytes] == o.encode(pcm[3, t0 + k][None])).all(), (t0, k)
 
 
+@pytest.mark.parametrize("fs,ms,hr,N,br", [(48000, 10.0, 0, 480, 64000), (48000, 10.0, 0, 480, 128000), (32000, 10.0, 0, 320, 96000),
+                                          (16000, 5.0, 0, 80, 32000), (96000, 2.5, 1, 240, 256000), (48000, 2.5, 0, 120, 160000)])
+def test_stage_traces_match_oracle(fs, ms, hr, N, br):
+    """Stage by stage, not only the final bytes: every intermediate the traced entry point records per channel-frame (MDCT spectrum,
+    12.8 kHz signal, pitch lag and correlation, LTPF parameters, attack flag, band energies, bandwidth, scale factors and their
+    indices, shaped and TNS-filtered spectra, TNS orders / indices / bits, both gains, bit counts, last non-zero line, quantised lines,
+    noise level, residual bit count, side-information cursor) equals the oracle's trace of the same frame exactly (floats bit for bit)."""
+    import ctypes as C
+    from lc3_harness import Trace
+    amd = _amd()
+    B, T = 6, 8
+    pcm = synth_pcm(B, T, N, fs, seed=31)
+    bt = amd.Batch(B, fs, 1, ms, hr, [br] * B, device=0)
+    got, traces = bt.encode_traced(pcm)
+    nb = bt.num_bytes(0)
+    bad = []
+    for b in range(B):
+        o = Oracle(fs, 1, ms, hr, br, portable_math=True)
+        tr = o.enable_trace()
+        for t in range(T):
+            want = o.encode(pcm[b, t][None])
+            assert (got[b, t, :nb] == want).all(), (b, t)
+            g = Trace.from_buffer_copy(traces[b * T + t].tobytes()[:C.sizeof(Trace)])
+            for f, _ in Trace._fields_:
+                ga, ca = getattr(g, f), getattr(tr[0], f)
+                if hasattr(ga, "__len__"):
+                    n = N if len(ga) == 960 else len(ga)
+                    a, c = np.ctypeslib.as_array(ga)[:n], np.ctypeslib.as_array(ca)[:n]
+                else:
+                    a, c = np.asarray([ga]), np.asarray([ca])
+                same = (a.view(np.uint32) == c.view(np.uint32)) if a.dtype.kind == "f" else (a == c)
+                if a.dtype.kind == "f": same = same | ((a == 0) & (c == 0))          # +0 / -0
+                if not same.all(): bad.append((b, t, f, int((~same).sum())))
+    assert not bad, bad[:10]
+
+
 def test_checkpoint_resume_state():
     """lc3plus_enc_batch_get_state / set_state: a second batch of the same configuration given the first one's state continues the
     streams byte for byte (MDCT / resampler memory, pitch and LTPF histories, rate-control and attack-detector words); mixed bitrates
