@@ -76,6 +76,8 @@ struct __attribute__((aligned(16))) WaveLds {
     static constexpr bool CDW = true;       /* st_quantize leaves the per-tuple coder words st_bitstream reads */
     static constexpr int MISC = 368;   /* = SM_MISC: where the scratch vectors of this layout's sm[] start */
     static constexpr int XOFF = MEMCAP; /* the frame half of xbuf (XCUR / XQ) */
+    static constexpr int TNS0 = 368, TNS1 = 240;   /* TNS work areas in sm[]: filter 0 from SM_MISC, filter 1 in the (idle) SM_PVQ area */
+    static constexpr int RESO = MAXN / 2, LSTO = MAXN / 2 + 2;   /* residual bits / noise-level list behind the coder words */
     float xbuf[MEMCAP + MAXN];  /* [MDCT/resampler memory right-aligned in 0..MEMCAP | current frame X]; once the MDCT fold has consumed the
                                    frame, X is scratch (DFT ping buffer, TNS output) and finally the quantised spectrum xq */
     float A[MAXN];              /* scratch, then the MDCT spectrum (shaped / TNS-filtered in place); the output frame during the bitstream stage */
@@ -116,7 +118,7 @@ struct __attribute__((aligned(16))) FrontLds {
 #define SPEC(L) ((L).A)
 #define BYTES(L) ((uint8_t*)(L).A)            /* up to 640 bytes, valid from the bitstream stage to the copy-out */
 #define CDW(L)  ((uint32_t*)&(L).sm[0])      /* per 2-tuple: ctx(10) | maxlev+1 (6) | pki of the final symbol (6) | sym (5) */
-#define RESB(L) ((uint8_t*)&(L).sm[MAXN / 2]) /* 640 bytes: residual bits / LSB-mode list (bit-packed, LSB first) */
+#define RESB(L) ((uint8_t*)&(L).sm[(L).RESO]) /* 640 bytes: residual bits / LSB-mode list (bit-packed, LSB first) */
 
 /* sm[] map (floats) before quantisation */
 #define SM_ENER   0     /* 64  band energies, later the interpolated SNS gains */
@@ -1543,8 +1545,9 @@ template <class LdsT> __device__ __forceinline__ TnsGeom tns_geom(LdsT& L, int b
 /* LPC weighting (total_bits < 480 only): polynomial weighting + step-down back to reflection coefficients,
  * R/tns_coder.c:91-155,279-287.  Rare and index-heavy: lane 0 works in LDS scratch sc[]: a_in[9] at 36, rc_in[8] at 46. */
 /* per-filter TNS scratch: work area sc[64] (LPC weighting 0..35, a[] 36.., rc[] 46.., predGain 63) and quantised rc[8] */
-#define TNS_SC(L, f)  (&(L).sm[(f) ? SM_PVQ : SM_MISC + 112])
-#define TNS_RCS(L, f) (&(L).sm[(f) ? SM_PVQ + 64 : SM_MISC + 104])
+#define TNS_SC(L, f)  (&(L).sm[(f) ? (L).TNS1 : (L).TNS0 + 112])
+#define TNS_RCS(L, f) (&(L).sm[(f) ? (L).TNS1 + 64 : (L).TNS0 + 104])
+#define TNS_RACC(L)   (&(L).sm[(L).TNS0])          /* [f][sub][k] sums (54), sub-division energies (6) at +54, r[f][9] at +64, lattice state (8) at +96 */
 
 template <class LdsT> STAGE void tns_lpc_weight(LdsT& L, int lane, int f, int maxOrder, float maxPG, float predGain)
 {
@@ -1586,7 +1589,7 @@ template <class LdsT> STAGE void tns_lpc_weight(LdsT& L, int lane, int f, int ma
 template <class LdsT> STAGE int tns_levinson(LdsT& L, int lane, int nf, int maxOrder, float maxPG)
 {
     const int f = lane & 1;
-    const float* racc = &L.sm[SM_MISC + 64 + f * 9];
+    const float* racc = TNS_RACC(L) + 64 + f * 9;
     float r[9], a[9], rc[8], buf[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) { r[i] = racc[i]; a[i] = 0; }
@@ -1668,7 +1671,7 @@ template <class LdsT> STAGE int tns_quant(LdsT& L, int lane, int nf, int maxOrde
 template <class LdsT> STAGE void tns_lattice(LdsT& L, int lane, int f, int b_first, int cnt, int ord)
 {
     f = uni(f); b_first = uni(b_first); cnt = uni(cnt); ord = uni(ord);
-    float* stt = &L.sm[SM_MISC + 96];
+    float* stt = TNS_RACC(L) + 96;
     const float* rcs = TNS_RCS(L, f);
     float* X = XCUR(L);
     float rc[8], st[8], carried[8];
@@ -1706,7 +1709,7 @@ template <class LdsT> STAGE void tns_lattice(LdsT& L, int lane, int f, int b_fir
 template <class LdsT> STAGE void tns_sums(LdsT& L, int lane, int bw_idx, int bw_bin)
 {
     const TnsGeom G = tns_geom(L, bw_idx, bw_bin);
-    float* racc = &L.sm[SM_MISC];              /* [f][sub][k] 2*3*9 = 54, sub-division energies 6 at +54, r[f][9] at +64 */
+    float* racc = TNS_RACC(L);                 /* [f][sub][k] 2*3*9 = 54, sub-division energies 6 at +54, r[f][9] at +64 */
     {   /* one serial sum per lane: lane (f, sub, k) < 54 owns autocorrelation lag k of a sub-division (R/tns_coder.c:18-39,258-277);
          * the sub-division energies are the lag-0 sums (same terms, same order).  Eight terms per block; the operands of the next
          * block are read before the arithmetic of the current one. */
@@ -1757,7 +1760,7 @@ template <class LdsT> STAGE void tns_sums(LdsT& L, int lane, int bw_idx, int bw_
         }
         racc[64 + lane] = r;
     }
-    if (lane >= 32 && lane < 40) L.sm[SM_MISC + 96 + lane - 32] = 0;     /* lattice state, persists from filter 0 to 1 */
+    if (lane >= 32 && lane < 40) TNS_RACC(L)[96 + lane - 32] = 0;     /* lattice state, persists from filter 0 to 1 */
     LSYNC();
 }
 
@@ -1941,6 +1944,48 @@ template <class LdsT> STAGE void st_gain_estimate(const lc3d_plan* __restrict__ 
     SUB(14);
 }
 
+/* ---- the stateless half of the global-gain estimate (R/estimate_global_gain.c:52-91): spectrum maximum -> smallest gain index,
+ * the high-resolution regulariser, the per-4-bin log energies en[].  Runs in lc3_enc_shape_kernel for all frames at once; the
+ * half that reads what the previous frame left (the rate loop and the bisection against its target, :42-50, :93-137) is
+ * lc3_enc_rate_kernel.  en[] goes to `en_out` (global, nq floats), ind_min and the all-zero flag to the record. ---- */
+template <class LdsT> STAGE void st_gain_prep(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ C, LdsT& L, int lane, float* __restrict__ en_out, float* __restrict__ rec)
+{
+    const int lg = PI(ylen), off = CI(gg_off), nq = lg >> 2;
+    float xm = 0;
+#pragma unroll
+    for (int k = 0; k < MAXN / WAVE + 1; k++) { const int i = lane + 64 * k; if (i < lg) xm = fmaxf(xm, fabsf(L.A[i])); }
+    const float x_max = unif(wave_max_f(xm));
+    float reg_val = 0;
+    if (PI(hrmode) && CI(reg_bits) > 0) {
+        float M0 = 1e-5f, M1 = 1e-5f; const float thresh = 2 * PF(frame_ms);
+        for (int i0 = 0; i0 < lg; i0 += WAVE) {                      /* R/estimate_global_gain.c:58-62, serial in double */
+            const int i = i0 + lane;
+            const double ax = i < lg ? fabs((double)L.A[i]) : 0.0, ix = (double)i * ax;
+            const int cnt = imin(WAVE, lg - i0);
+            for (int k = 0; k < cnt; k++) { M0 = (float)((double)M0 + rl_d(ax, k)); M1 = (float)((double)M1 + rl_d(ix, k)); }
+        }
+        const float q = M1 / M0;
+        const float rB = 8 * (1 - (q < thresh ? q : thresh) / thresh);
+        reg_val = x_max * m_powf(2.0f, (float)(-CI(reg_bits)) - rB);
+    }
+    float ind_min = (float)off;
+    if (x_max != 0) {
+        const float g_min = PI(hrmode) == 1 ? x_max / (float)(32768 * 256 - 2) : (float)((double)x_max / (32768 - 0.375));
+        ind_min = (float)ceil(28.0 * (double)m_log10f(g_min));
+#pragma unroll
+        for (int h = 0; h < NQL; h++) {
+            const int j = lane + 64 * h;
+            if (j < nq) {
+                const float* x = &L.A[4 * j];
+                float t = x[0] * x[0];
+                t += x[1] * x[1]; t += x[2] * x[2]; t += x[3] * x[3];
+                en_out[j] = (float)((28.0 / 20.0) * (7 + 10.0 * (double)m_log10f(t + reg_val + PF(c_2m31))));
+            }
+        }
+    }
+    if (lane == 0) { rec[FR_GGMIN] = ind_min; ((int*)rec)[FR_XZERO] = x_max == 0 ? 1 : 0; }
+}
+
 /* ---- quantisation + exact bit estimate R/quantize_spec.c:26-197 ---- */
 template <class LdsT> STAGE void st_quantize(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ C, LdsT& L, int lane, int mode, int target)
 {
@@ -1981,6 +2026,11 @@ template <class LdsT> STAGE void st_quantize(const lc3d_plan* __restrict__ P, co
     for (int k = 0; k < MAXN / 2 / WAVE + 1; k++) { const int p = lane + 64 * k; if (p < (nt >> 1) && p >= 1 && (xq[2 * p] != 0 || xq[2 * p + 1] != 0)) lp = p; }
     lp = uni(wave_max_i(lp));
     const int lastnz = lp >= 1 ? 2 * lp + 1 : 1;
+    if (mode == -2) {                             /* lc3_enc_tail_kernel, gain unchanged: the lines only; the bit count of this quantisation came from lc3_enc_rate_kernel */
+        if (lane == 0) { L.isc[I_LSB] = 0; L.isc[I_LASTNZ] = lastnz + 1; }
+        LSYNC();
+        return;
+    }
     const int ntup = (lastnz + 1) >> 1;
     int lastnz2 = mode < 0 ? lastnz + 1 : 2;
     int nbits2 = 0, base = 0, nlsb = 0, ct1 = 0, ct2 = 0;
@@ -2153,7 +2203,7 @@ template <class LdsT> STAGE void st_noise_factor(const lc3d_plan* __restrict__ P
         return;
     }
     if (!split) {
-        float* lst = &L.sm[MAXN / 2 + 2];           /* >= 306 free words (16-byte aligned): the residual-bit area is not in use yet */
+        float* lst = &L.sm[L.LSTO];               /* >= 208 free words (16-byte aligned): the residual-bit area is not in use yet */
         j1 = nz;
 #pragma unroll
         for (int g = 0; g < 8; g += 3) {
@@ -2815,7 +2865,8 @@ KERNEL_NAME(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans
 /* C-ABI device shim (lc3_shim.h): context, uploads, launch                                          */
 /* ------------------------------------------------------------------------------------------------ */
 #include "lc3_enc_front.inc"       /* lc3_enc_front_kernel (or _big): the stateless front, frame-parallel */
-#include "lc3_enc_seq.inc"         /* lc3_enc_pitch_kernel, lc3_enc_seq_kernel (or _big): the two sequential kernels of the pipelined path */
+#include "lc3_enc_seq.inc"         /* lc3_enc_pitch_kernel: the pitch chain of the pipelined path */
+#include "lc3_enc_rate.inc"        /* lc3_enc_shape_kernel, lc3_enc_rate_kernel, lc3_enc_tail_kernel (or _big): the rate chain and its frame-parallel neighbours */
 #include "lc3_dec_kernels.inc"     /* lc3_dec_{plc,imdct,synth}_kernel, or the _big imdct / synth kernels in the large-layout object */
 #ifndef LC3_BIG                 /* the large-layout object holds only its kernels */
 #include "lc3_dec_parse.inc"
@@ -2825,10 +2876,14 @@ extern "C" __global__ void lc3_encode_kernel_big(const lc3d_plan* __restrict__ P
                                                  uint8_t* __restrict__ status, int dT, int dt0, const float* __restrict__ spec, const float* __restrict__ frec,
                                                  const float* __restrict__ xnext);
 extern "C" __global__ void lc3_enc_front_kernel_big(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans, const float* __restrict__ state, const void* __restrict__ pcm,
-                                                    int bitdepth, int T, int tb, int nt, int fpw, int ncs, float* __restrict__ spec, float* __restrict__ rec, float* __restrict__ xnext, const float* __restrict__ xprev, int xprev_stride);
-extern "C" __global__ void lc3_enc_seq_kernel_big(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans, float* __restrict__ state, int T, int t0, int nt, int ncs,
-                                                  int* __restrict__ dump, int dstride, int dT, int dt0, uint8_t* __restrict__ status, const float* __restrict__ spec,
-                                                  const float* __restrict__ frec, const float* __restrict__ xnext);
+                                                    int bitdepth, int T, int tb, int nt, int fpw, int ncs, float* __restrict__ spec, int srow, float* __restrict__ rec, float* __restrict__ xnext, const float* __restrict__ xprev, int xprev_stride);
+extern "C" __global__ void lc3_enc_shape_kernel_big(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans, int T, int tb, int nt, int fpw, int ncs,
+                                                    float* __restrict__ rows, int srow, float* __restrict__ frec);
+extern "C" __global__ void lc3_enc_rate_kernel_big(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans, float* __restrict__ state, int T, int t0, int nt, int ncs,
+                                                   const float* __restrict__ rows, int srow, float* __restrict__ frec, const float* __restrict__ xnext);
+extern "C" __global__ void lc3_enc_tail_kernel_big(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans, int T, int tb, int nt, int fpw, int ncs,
+                                                   const float* __restrict__ rows, int srow, const float* __restrict__ frec, int* __restrict__ dump, int dstride, int dT, int dt0,
+                                                   uint8_t* __restrict__ status);
 #include "lc3_enc_pack.inc"
 #include "lc3_enc_snsvq.inc"
 #include "lc3_enc_pre.inc"
@@ -2847,7 +2902,8 @@ struct lc3hip_ctx {
     /* host-pointer pipeline (lc3hip_encode_host): two chunk slots, each with device staging and (for pageable callers) pinned staging */
     void* hp_dpcm[2]; void* hp_pin_in[2]; size_t hp_pcm_cap, hp_pin_in_cap;
     hipStream_t s_h2d; hipEvent_t ev_h2d[2], ev_k[2];
-    hipStream_t s_pre, s_fr; hipEvent_t ev_fork, ev_p[LC3D_MAX_RUNS], ev_f[LC3D_MAX_RUNS];
+    hipStream_t s_pre, s_fr, s_tl; hipEvent_t ev_fork, ev_p[LC3D_MAX_RUNS], ev_f[LC3D_MAX_RUNS], ev_r[LC3D_MAX_RUNS], ev_t;   /* side streams: pitch chain, frame-parallel front, frame-parallel tail */
+    int ylen, srow;
     hipStream_t stream, last_stream; hipEvent_t ev0, ev1; float last_ms;
 };
 
@@ -2870,7 +2926,7 @@ extern "C" int lc3hip_create(void** out_ctx, const lc3d_plan* plan, int n_stream
     HIPCHK_OR(hipSetDevice(device), free(c));
     c->n_streams = n_streams; c->channels = plan->channels; c->ncs = n_streams * plan->channels; c->N = plan->N;
     c->big = LC3D_LAYOUT_BIG(plan->N, plan->la);
-    c->hr = plan->hrmode;
+    c->hr = plan->hrmode; c->ylen = plan->ylen; c->srow = LC3D_SROW(plan->ylen);
     { const char* e = getenv("LC3PLUS_ENC_FUSED"); c->fused = e && e[0] == '1'; }     /* diagnostic: the bitstream writer inside lc3_encode_kernel */
     c->state_words = LC3D_STATE_WORDS(c->big ? LC3D_MEMCAP_BIG : LC3D_MEMCAP_STD);
     HIPCHK_OR(hipMalloc((void**)&c->d_plan, sizeof(lc3d_plan)), lc3hip_destroy(c));
@@ -2981,14 +3037,14 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
          * LTPF one stream per wave), on another the frame-parallel front (MDCT ... scale factors), the attack decision and the SNS
          * quantiser (one frame per lane); on the launch stream the rate chain (lc3_enc_seq_kernel), which waits for both.  The side kernels
          * of run k+1 are resident beside the rate kernel of run k (they were sized for that: lc3_enc_seq.inc). */
-        const size_t ns = (size_t)c->ncs * n_frames * c->N, nr = (size_t)c->ncs * n_frames * FR_WORDS;
+        const size_t ns = (size_t)c->ncs * n_frames * c->srow, nr = (size_t)c->ncs * n_frames * FR_WORDS;
         if (c->spec_cap < ns) { if (c->d_spec) HIPCHK(hipFree(c->d_spec)); c->d_spec = nullptr; c->spec_cap = 0; HIPCHK(hipMalloc((void**)&c->d_spec, ns * sizeof(float))); c->spec_cap = ns; }
         if (c->frec_cap < nr) { if (c->d_frec) HIPCHK(hipFree(c->d_frec)); c->d_frec = nullptr; c->frec_cap = 0; HIPCHK(hipMalloc((void**)&c->d_frec, nr * sizeof(float))); c->frec_cap = nr; }
         for (int i = 0; i < 2; i++) if (!c->d_xnext[i]) HIPCHK(hipMalloc((void**)&c->d_xnext[i], (size_t)c->ncs * mc * sizeof(float)));
         if (!c->s_pre) {
-            HIPCHK(hipStreamCreateWithFlags(&c->s_pre, hipStreamNonBlocking)); HIPCHK(hipStreamCreateWithFlags(&c->s_fr, hipStreamNonBlocking));
-            HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-            for (int i = 0; i < LC3D_MAX_RUNS; i++) { HIPCHK(hipEventCreateWithFlags(&c->ev_p[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_f[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_s[i], hipEventDisableTiming)); }
+            HIPCHK(hipStreamCreateWithFlags(&c->s_pre, hipStreamNonBlocking)); HIPCHK(hipStreamCreateWithFlags(&c->s_fr, hipStreamNonBlocking)); HIPCHK(hipStreamCreateWithFlags(&c->s_tl, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_t, hipEventDisableTiming));
+            for (int i = 0; i < LC3D_MAX_RUNS; i++) { HIPCHK(hipEventCreateWithFlags(&c->ev_p[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_f[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_s[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_r[i], hipEventDisableTiming)); }
         }
         float* dspec = c->d_spec; float* dfrec = c->d_frec;
         static int runf = 0;
@@ -3038,20 +3094,42 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
             HIPCHK(hipEventRecord(c->ev_p[k], c->s_pre));
             const int fpw = nt < FRONT_FPW ? nt : FRONT_FPW;
             const unsigned fruns = (unsigned)((nt + fpw - 1) / fpw);
-            if (c->big) hipLaunchKernelGGL(lc3_enc_front_kernel_big, dim3((unsigned)c->ncs * fruns), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames, tb, nt, fpw, c->ncs, dspec, dfrec, xn_w, xprev, xprev_stride);
-            else DUPL('f') hipLaunchKernelGGL(lc3_enc_front_kernel, dim3((unsigned)c->ncs * fruns), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames, tb, nt, fpw, c->ncs, dspec, dfrec, xn_w, xprev, xprev_stride);
+            if (c->big) hipLaunchKernelGGL(lc3_enc_front_kernel_big, dim3((unsigned)c->ncs * fruns), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames, tb, nt, fpw, c->ncs, dspec, c->srow, dfrec, xn_w, xprev, xprev_stride);
+            else DUPL('f') hipLaunchKernelGGL(lc3_enc_front_kernel, dim3((unsigned)c->ncs * fruns), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames, tb, nt, fpw, c->ncs, dspec, c->srow, dfrec, xn_w, xprev, xprev_stride);
             if (c->any_attack)
                 hipLaunchKernelGGL(lc3_enc_attack_kernel, dim3((unsigned)((c->ncs + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, c->state_words, LC3D_ST_SCAL(mc), dfrec, n_frames, tb, nt, c->ncs);
             const long long nfr = (long long)c->ncs * nt;
             DUPL('v') hipLaunchKernelGGL(lc3_enc_snsvq_kernel, dim3((unsigned)((nfr + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->s_fr, c->d_plan, dfrec, n_frames, tb, nt, c->ncs, c->any_attack);
+            {   /* shaping, TNS and the stateless half of the gain estimate: frame-parallel, behind the quantiser */
+                static int sfpw = 0;
+                if (!sfpw) { const char* e = getenv("LC3PLUS_ENC_SHAPE_FPW"); sfpw = e && atoi(e) >= 1 ? atoi(e) : SHAPE_FPW; }     /* diagnostic */
+                const int spw = nt < sfpw ? nt : sfpw;
+                const unsigned sruns = (unsigned)((nt + spw - 1) / spw);
+                if (c->big) hipLaunchKernelGGL(lc3_enc_shape_kernel_big, dim3((unsigned)c->ncs * sruns), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, n_frames, tb, nt, spw, c->ncs, dspec, c->srow, dfrec);
+                else DUPL('a') hipLaunchKernelGGL(lc3_enc_shape_kernel, dim3((unsigned)c->ncs * sruns), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, n_frames, tb, nt, spw, c->ncs, dspec, c->srow, dfrec);
+            }
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(c->ev_f[k], c->s_fr));
             HIPCHK(hipStreamWaitEvent(s, c->ev_p[k], 0)); HIPCHK(hipStreamWaitEvent(s, c->ev_f[k], 0));
-            if (c->big) hipLaunchKernelGGL(lc3_enc_seq_kernel_big, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, n_frames, tb, nt, c->ncs, ddump, dstride, dT, dt0, c->d_status, dspec, dfrec, xn_w);
-            else DUPL('s') hipLaunchKernelGGL(lc3_enc_seq_kernel, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, n_frames, tb, nt, c->ncs, ddump, dstride, dT, dt0, c->d_status, dspec, dfrec, xn_w);
+            if (c->big) hipLaunchKernelGGL(lc3_enc_rate_kernel_big, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, n_frames, tb, nt, c->ncs, dspec, c->srow, dfrec, xn_w);
+            else DUPL('s') hipLaunchKernelGGL(lc3_enc_rate_kernel, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, n_frames, tb, nt, c->ncs, dspec, c->srow, dfrec, xn_w);
             HIPCHK(hipGetLastError());
-            if (c->input_ready && n_frames <= amax) HIPCHK(hipEventRecord(c->ev_s[k], s));
+            HIPCHK(hipEventRecord(c->ev_r[k], s));
+            {   /* behind the chain, frame-parallel again on a stream of its own: gain adjustment, second quantisation, noise level, residual, pack record */
+                static int tfpw = 0;
+                if (!tfpw) { const char* e = getenv("LC3PLUS_ENC_TAIL_FPW"); tfpw = e && atoi(e) >= 1 ? atoi(e) : TAIL_FPW; }     /* diagnostic */
+                const int tpw = nt < tfpw ? nt : tfpw;
+                const unsigned truns = (unsigned)((nt + tpw - 1) / tpw);
+                HIPCHK(hipStreamWaitEvent(c->s_tl, c->ev_r[k], 0));
+                if (c->big) hipLaunchKernelGGL(lc3_enc_tail_kernel_big, dim3((unsigned)c->ncs * truns), dim3(WAVE), 0, c->s_tl, c->d_plan, c->d_chans, n_frames, tb, nt, tpw, c->ncs, dspec, c->srow, dfrec, ddump, dstride, dT, dt0, c->d_status);
+                else DUPL('t') hipLaunchKernelGGL(lc3_enc_tail_kernel, dim3((unsigned)c->ncs * truns), dim3(WAVE), 0, c->s_tl, c->d_plan, c->d_chans, n_frames, tb, nt, tpw, c->ncs, dspec, c->srow, dfrec, ddump, dstride, dT, dt0, c->d_status);
+                HIPCHK(hipGetLastError());
+                /* the tail kernel is the last reader of the run's rows and records: the next call's side kernels of run k wait for it */
+                if (c->input_ready && n_frames <= amax) HIPCHK(hipEventRecord(c->ev_s[k], c->s_tl));
+            }
         }
+        HIPCHK(hipEventRecord(c->ev_t, c->s_tl));
+        HIPCHK(hipStreamWaitEvent(s, c->ev_t, 0));       /* everything of the call is behind s again */
         c->ahead_ok = (dt0 == 0 && dT == n_frames && pack) ? 1 : 0; c->ahead_T = n_frames; c->ahead_R = R; c->xn_par ^= 1;
     }
     if (ddump && pack) {
@@ -3244,8 +3322,8 @@ extern "C" int lc3hip_destroy(void* ctx)
         if (c->ev_k[i]) hipEventDestroy(c->ev_k[i]);
     }
     if (c->s_h2d) hipStreamDestroy(c->s_h2d);
-    if (c->s_pre) { hipStreamDestroy(c->s_pre); hipStreamDestroy(c->s_fr); hipEventDestroy(c->ev_fork);
-                    for (int i = 0; i < LC3D_MAX_RUNS; i++) { hipEventDestroy(c->ev_p[i]); hipEventDestroy(c->ev_f[i]); hipEventDestroy(c->ev_s[i]); } }
+    if (c->s_pre) { hipStreamDestroy(c->s_pre); hipStreamDestroy(c->s_fr); hipStreamDestroy(c->s_tl); hipEventDestroy(c->ev_fork); hipEventDestroy(c->ev_t);
+                    for (int i = 0; i < LC3D_MAX_RUNS; i++) { hipEventDestroy(c->ev_p[i]); hipEventDestroy(c->ev_f[i]); hipEventDestroy(c->ev_s[i]); hipEventDestroy(c->ev_r[i]); } }
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); }

@@ -85,7 +85,15 @@ typedef struct {
 #define FR_ATTM  44
 #define FR_ATTFLAG 46
 #define FR_LTPF  48                      /* 4 ints from lc3_enc_pitch_kernel: LTPF flag, active, pitch index, side bits (R/ltpf_coder.c:245-254) */
-#define FR_WORDS 52
+#define FR_TNS   52                      /* 20 ints from lc3_enc_shape_kernel: filters, orders (2), bits, coefficient indices (16) = isc[I_TNS_NF ...] (R/tns_coder.c) */
+#define FR_GGMIN 72                      /* float: smallest gain index of the frame, before the offset (R/estimate_global_gain.c:72-77) */
+#define FR_XZERO 73                      /* int: the shaped spectrum is all zero (:65-70) */
+#define FR_BWC   74                      /* int: bandwidth index behind the bandwidth controller (R/cutoff_bandwidth.c) */
+#define FR_RATE  76                      /* 4 words from lc3_enc_rate_kernel: gain index (int), gain (float), bits of the first quantisation, its lastnz */
+#define FR_WORDS 80
+/* spectrum row of the pipelined encoder path, per channel-frame: [0, ylen) the MDCT spectrum (lc3_enc_front_kernel), shaped and TNS-filtered in
+ * place by lc3_enc_shape_kernel, which appends the ylen / 4 log energies of the gain estimate; rows are SROW words apart */
+#define LC3D_SROW(ylen) (((ylen) + ((ylen) >> 2) + 15) & ~15)
 
 /* per channel-frame status bits of the encoder: conditions the reference only asserts on (SURVEY 5 "failure detection") */
 #define LC3D_ENC_ST_BIT_BUDGET  1        /* side information + range-coder bits exceed the frame (R/ari_codec.c:777) */
