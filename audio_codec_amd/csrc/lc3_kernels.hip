@@ -2902,7 +2902,7 @@ struct lc3hip_ctx {
     /* host-pointer pipeline (lc3hip_encode_host): two chunk slots, each with device staging and (for pageable callers) pinned staging */
     void* hp_dpcm[2]; void* hp_pin_in[2]; size_t hp_pcm_cap, hp_pin_in_cap;
     hipStream_t s_h2d; hipEvent_t ev_h2d[2], ev_k[2];
-    hipStream_t s_pre, s_fr, s_tl; hipEvent_t ev_fork, ev_p[LC3D_MAX_RUNS], ev_f[LC3D_MAX_RUNS], ev_r[LC3D_MAX_RUNS], ev_t;   /* side streams: pitch chain, frame-parallel front, frame-parallel tail */
+    hipStream_t s_pre, s_fr; hipEvent_t ev_fork, ev_p[LC3D_MAX_RUNS], ev_f[LC3D_MAX_RUNS], ev_r[LC3D_MAX_RUNS], ev_t;   /* side streams: pitch chain, frame-parallel front, frame-parallel tail */
     int ylen, srow;
     hipStream_t stream, last_stream; hipEvent_t ev0, ev1; float last_ms;
 };
@@ -2933,7 +2933,8 @@ extern "C" int lc3hip_create(void** out_ctx, const lc3d_plan* plan, int n_stream
     HIPCHK_OR(hipMemcpy(c->d_plan, plan, sizeof(lc3d_plan), hipMemcpyHostToDevice), lc3hip_destroy(c));
     HIPCHK_OR(hipMalloc((void**)&c->d_chans, sizeof(lc3d_chan) * c->ncs), lc3hip_destroy(c));
     HIPCHK_OR(hipMalloc((void**)&c->d_state, sizeof(float) * c->state_words * (size_t)c->ncs), lc3hip_destroy(c));
-    HIPCHK_OR(hipStreamCreate(&c->stream), lc3hip_destroy(c));
+    /* the library's own launch stream is created when a call first needs it (a caller that brings its stream never does): HIP maps streams
+     * onto a few hardware queues, and the pipelined path wants its three side streams on queues of their own */
     HIPCHK_OR(hipEventCreate(&c->ev0), lc3hip_destroy(c)); HIPCHK_OR(hipEventCreate(&c->ev1), lc3hip_destroy(c));
     *out_ctx = c;
     return 0;
@@ -3042,7 +3043,7 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
         if (c->frec_cap < nr) { if (c->d_frec) HIPCHK(hipFree(c->d_frec)); c->d_frec = nullptr; c->frec_cap = 0; HIPCHK(hipMalloc((void**)&c->d_frec, nr * sizeof(float))); c->frec_cap = nr; }
         for (int i = 0; i < 2; i++) if (!c->d_xnext[i]) HIPCHK(hipMalloc((void**)&c->d_xnext[i], (size_t)c->ncs * mc * sizeof(float)));
         if (!c->s_pre) {
-            HIPCHK(hipStreamCreateWithFlags(&c->s_pre, hipStreamNonBlocking)); HIPCHK(hipStreamCreateWithFlags(&c->s_fr, hipStreamNonBlocking)); HIPCHK(hipStreamCreateWithFlags(&c->s_tl, hipStreamNonBlocking));
+            HIPCHK(hipStreamCreateWithFlags(&c->s_pre, hipStreamNonBlocking)); HIPCHK(hipStreamCreateWithFlags(&c->s_fr, hipStreamNonBlocking));
             HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_t, hipEventDisableTiming));
             for (int i = 0; i < LC3D_MAX_RUNS; i++) { HIPCHK(hipEventCreateWithFlags(&c->ev_p[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_f[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_s[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_r[i], hipEventDisableTiming)); }
         }
@@ -3076,6 +3077,17 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
          * kernel should start early), then four runs at a time, in stream order between the pitch kernels that need them.  (More side
          * streams than these two do not help: HIP multiplexes streams onto a few hardware queues and kernels of two streams that share
          * one run back to back.) */
+        int run_tb[LC3D_MAX_RUNS], run_nt[LC3D_MAX_RUNS], nruns = 0;
+        static int tfpw = 0;
+        if (!tfpw) { const char* e = getenv("LC3PLUS_ENC_TAIL_FPW"); tfpw = e && atoi(e) >= 1 ? atoi(e) : TAIL_FPW; }     /* diagnostic */
+#define LAUNCH_TAIL(k_) do { const int tb_ = run_tb[k_], nt_ = run_nt[k_]; \
+            const int tpw = nt_ < tfpw ? nt_ : tfpw; const unsigned truns = (unsigned)((nt_ + tpw - 1) / tpw); \
+            HIPCHK(hipStreamWaitEvent(c->s_fr, c->ev_r[k_], 0)); \
+            if (c->big) hipLaunchKernelGGL(lc3_enc_tail_kernel_big, dim3((unsigned)c->ncs * truns), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, n_frames, tb_, nt_, tpw, c->ncs, dspec, c->srow, dfrec, ddump, dstride, dT, dt0, c->d_status); \
+            else DUPL('t') hipLaunchKernelGGL(lc3_enc_tail_kernel, dim3((unsigned)c->ncs * truns), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, n_frames, tb_, nt_, tpw, c->ncs, dspec, c->srow, dfrec, ddump, dstride, dT, dt0, c->d_status); \
+            HIPCHK(hipGetLastError()); \
+            /* the tail kernel is the last reader of the run's rows and records: the next call's side kernels of run k wait for it */ \
+            if (c->input_ready && n_frames <= amax) HIPCHK(hipEventRecord(c->ev_s[k_], c->s_fr)); } while (0)
         for (int k = 0, tb = 0, hb = 0, hk = 0; tb < n_frames; k++, tb += Tr) {
             const int nt = n_frames - tb < Tr ? n_frames - tb : Tr;
             if (ahead) { HIPCHK(hipStreamWaitEvent(c->s_pre, c->ev_s[k], 0)); HIPCHK(hipStreamWaitEvent(c->s_fr, c->ev_s[k], 0)); }
@@ -3100,36 +3112,33 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
                 hipLaunchKernelGGL(lc3_enc_attack_kernel, dim3((unsigned)((c->ncs + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, c->state_words, LC3D_ST_SCAL(mc), dfrec, n_frames, tb, nt, c->ncs);
             const long long nfr = (long long)c->ncs * nt;
             DUPL('v') hipLaunchKernelGGL(lc3_enc_snsvq_kernel, dim3((unsigned)((nfr + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->s_fr, c->d_plan, dfrec, n_frames, tb, nt, c->ncs, c->any_attack);
-            {   /* shaping, TNS and the stateless half of the gain estimate: frame-parallel, behind the quantiser */
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(c->ev_f[k], c->s_fr));
+            if (k >= 2) LAUNCH_TAIL(k - 2);
+            HIPCHK(hipStreamWaitEvent(s, c->ev_f[k], 0));
+            {   /* shaping, TNS and the stateless half of the gain estimate: frame-parallel, behind the quantiser; on the launch stream in front
+                 * of the rate kernel (which is short): the front / quantiser stream and this one then carry about the same load per run */
                 static int sfpw = 0;
                 if (!sfpw) { const char* e = getenv("LC3PLUS_ENC_SHAPE_FPW"); sfpw = e && atoi(e) >= 1 ? atoi(e) : SHAPE_FPW; }     /* diagnostic */
                 const int spw = nt < sfpw ? nt : sfpw;
                 const unsigned sruns = (unsigned)((nt + spw - 1) / spw);
-                if (c->big) hipLaunchKernelGGL(lc3_enc_shape_kernel_big, dim3((unsigned)c->ncs * sruns), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, n_frames, tb, nt, spw, c->ncs, dspec, c->srow, dfrec);
-                else DUPL('a') hipLaunchKernelGGL(lc3_enc_shape_kernel, dim3((unsigned)c->ncs * sruns), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, n_frames, tb, nt, spw, c->ncs, dspec, c->srow, dfrec);
+                if (c->big) hipLaunchKernelGGL(lc3_enc_shape_kernel_big, dim3((unsigned)c->ncs * sruns), dim3(WAVE), 0, s, c->d_plan, c->d_chans, n_frames, tb, nt, spw, c->ncs, dspec, c->srow, dfrec);
+                else DUPL('a') hipLaunchKernelGGL(lc3_enc_shape_kernel, dim3((unsigned)c->ncs * sruns), dim3(WAVE), 0, s, c->d_plan, c->d_chans, n_frames, tb, nt, spw, c->ncs, dspec, c->srow, dfrec);
             }
-            HIPCHK(hipGetLastError());
-            HIPCHK(hipEventRecord(c->ev_f[k], c->s_fr));
-            HIPCHK(hipStreamWaitEvent(s, c->ev_p[k], 0)); HIPCHK(hipStreamWaitEvent(s, c->ev_f[k], 0));
+            HIPCHK(hipStreamWaitEvent(s, c->ev_p[k], 0));
             if (c->big) hipLaunchKernelGGL(lc3_enc_rate_kernel_big, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, n_frames, tb, nt, c->ncs, dspec, c->srow, dfrec, xn_w);
             else DUPL('s') hipLaunchKernelGGL(lc3_enc_rate_kernel, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, n_frames, tb, nt, c->ncs, dspec, c->srow, dfrec, xn_w);
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(c->ev_r[k], s));
-            {   /* behind the chain, frame-parallel again on a stream of its own: gain adjustment, second quantisation, noise level, residual, pack record */
-                static int tfpw = 0;
-                if (!tfpw) { const char* e = getenv("LC3PLUS_ENC_TAIL_FPW"); tfpw = e && atoi(e) >= 1 ? atoi(e) : TAIL_FPW; }     /* diagnostic */
-                const int tpw = nt < tfpw ? nt : tfpw;
-                const unsigned truns = (unsigned)((nt + tpw - 1) / tpw);
-                HIPCHK(hipStreamWaitEvent(c->s_tl, c->ev_r[k], 0));
-                if (c->big) hipLaunchKernelGGL(lc3_enc_tail_kernel_big, dim3((unsigned)c->ncs * truns), dim3(WAVE), 0, c->s_tl, c->d_plan, c->d_chans, n_frames, tb, nt, tpw, c->ncs, dspec, c->srow, dfrec, ddump, dstride, dT, dt0, c->d_status);
-                else DUPL('t') hipLaunchKernelGGL(lc3_enc_tail_kernel, dim3((unsigned)c->ncs * truns), dim3(WAVE), 0, c->s_tl, c->d_plan, c->d_chans, n_frames, tb, nt, tpw, c->ncs, dspec, c->srow, dfrec, ddump, dstride, dT, dt0, c->d_status);
-                HIPCHK(hipGetLastError());
-                /* the tail kernel is the last reader of the run's rows and records: the next call's side kernels of run k wait for it */
-                if (c->input_ready && n_frames <= amax) HIPCHK(hipEventRecord(c->ev_s[k], c->s_tl));
-            }
+            run_tb[k] = tb; run_nt[k] = nt; nruns = k + 1;
         }
-        HIPCHK(hipEventRecord(c->ev_t, c->s_tl));
+        /* behind the chain, frame-parallel again: gain adjustment, second quantisation, noise level, residual, pack record.  On the front's stream,
+         * two runs late, so that its wait for the rate kernel never holds that stream up (HIP maps streams onto a few hardware queues: a side
+         * stream of its own shared one with the front's and stalled it at every wait) */
+        for (int k = nruns < 2 ? 0 : nruns - 2; k < nruns; k++) LAUNCH_TAIL(k);
+        HIPCHK(hipEventRecord(c->ev_t, c->s_fr));
         HIPCHK(hipStreamWaitEvent(s, c->ev_t, 0));       /* everything of the call is behind s again */
+#undef LAUNCH_TAIL
         c->ahead_ok = (dt0 == 0 && dT == n_frames && pack) ? 1 : 0; c->ahead_T = n_frames; c->ahead_R = R; c->xn_par ^= 1;
     }
     if (ddump && pack) {
@@ -3211,6 +3220,7 @@ extern "C" int lc3hip_encode(void* ctx, const void* pcm, int pcm_on_device, int 
 {
     lc3hip_ctx* c = (lc3hip_ctx*)ctx;
     HIPCHK(hipSetDevice(c->device));
+    if (!hip_stream && !c->stream) HIPCHK(hipStreamCreate(&c->stream));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
     if (!pcm_on_device && !out_on_device && !trace_host) return encode_host(c, pcm, bitdepth, n_frames, out, out_stride, s);
     const size_t bps = bitdepth == 16 ? 2 : 4;
@@ -3322,7 +3332,7 @@ extern "C" int lc3hip_destroy(void* ctx)
         if (c->ev_k[i]) hipEventDestroy(c->ev_k[i]);
     }
     if (c->s_h2d) hipStreamDestroy(c->s_h2d);
-    if (c->s_pre) { hipStreamDestroy(c->s_pre); hipStreamDestroy(c->s_fr); hipStreamDestroy(c->s_tl); hipEventDestroy(c->ev_fork); hipEventDestroy(c->ev_t);
+    if (c->s_pre) { hipStreamDestroy(c->s_pre); hipStreamDestroy(c->s_fr); hipEventDestroy(c->ev_fork); hipEventDestroy(c->ev_t);
                     for (int i = 0; i < LC3D_MAX_RUNS; i++) { hipEventDestroy(c->ev_p[i]); hipEventDestroy(c->ev_f[i]); hipEventDestroy(c->ev_s[i]); hipEventDestroy(c->ev_r[i]); } }
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
