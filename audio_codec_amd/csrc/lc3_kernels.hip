@@ -2876,14 +2876,11 @@ extern "C" __global__ void lc3_encode_kernel_big(const lc3d_plan* __restrict__ P
                                                  uint8_t* __restrict__ status, int dT, int dt0, const float* __restrict__ spec, const float* __restrict__ frec,
                                                  const float* __restrict__ xnext);
 extern "C" __global__ void lc3_enc_front_kernel_big(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans, const float* __restrict__ state, const void* __restrict__ pcm,
-                                                    int bitdepth, int T, int tb, int nt, int fpw, int ncs, float* __restrict__ spec, int srow, float* __restrict__ rec, float* __restrict__ xnext, const float* __restrict__ xprev, int xprev_stride);
+                                                    int bitdepth, int T, int tb, int nt, int fpw, int ncs, float* __restrict__ spec, int srow, int RT, int r0, float* __restrict__ rec, float* __restrict__ xnext, const float* __restrict__ xprev, int xprev_stride);
 extern "C" __global__ void lc3_enc_shape_kernel_big(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans, int T, int tb, int nt, int fpw, int ncs,
                                                     float* __restrict__ rows, int srow, float* __restrict__ frec);
 extern "C" __global__ void lc3_enc_rate_kernel_big(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans, float* __restrict__ state, int T, int t0, int nt, int ncs,
-                                                   const float* __restrict__ rows, int srow, float* __restrict__ frec, const float* __restrict__ xnext);
-extern "C" __global__ void lc3_enc_tail_kernel_big(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans, int T, int tb, int nt, int fpw, int ncs,
-                                                   const float* __restrict__ rows, int srow, const float* __restrict__ frec, int* __restrict__ dump, int dstride, int dT, int dt0,
-                                                   uint8_t* __restrict__ status);
+                                                   const float* __restrict__ rows, int srow, float* __restrict__ frec, const float* __restrict__ xnext, int last);
 #include "lc3_enc_pack.inc"
 #include "lc3_enc_snsvq.inc"
 #include "lc3_enc_pre.inc"
@@ -2897,12 +2894,12 @@ struct lc3hip_ctx {
     lc3d_trace* d_trace; size_t trace_cap;
     int* d_dump; size_t dump_cap; int hr, fused; float* d_y12; size_t y12_cap;
     uint8_t* d_status; size_t status_cap; int status_frames;
-    float* d_spec; size_t spec_cap; float* d_frec; size_t frec_cap; float* d_xnext[2]; int xn_par; uint8_t* h_attack; int any_attack;
-    int input_ready, ahead_ok, ahead_T, ahead_R; hipEvent_t ev_s[LC3D_MAX_RUNS];   /* lc3hip_set_input_ready: side kernels of a call beside the previous call's tail */   /* split path (lc3_enc_front.inc) */      /* per channel-frame status bits of the last call (LC3D_ENC_ST_*) */
+    float* d_spec[2]; size_t spec_cap[2]; float* d_frec[2]; size_t frec_cap[2]; hipEvent_t ev_done[2]; float* d_xnext[2]; int xn_par, row_par; uint8_t* h_attack; int any_attack;
+    int input_ready, ahead_ok, ahead_T, ahead_R;   /* lc3hip_set_input_ready: side kernels of a call beside the previous call's tail */   /* split path (lc3_enc_front.inc) */      /* per channel-frame status bits of the last call (LC3D_ENC_ST_*) */
     /* host-pointer pipeline (lc3hip_encode_host): two chunk slots, each with device staging and (for pageable callers) pinned staging */
     void* hp_dpcm[2]; void* hp_pin_in[2]; size_t hp_pcm_cap, hp_pin_in_cap;
     hipStream_t s_h2d; hipEvent_t ev_h2d[2], ev_k[2];
-    hipStream_t s_pre, s_fr; hipEvent_t ev_fork, ev_p[LC3D_MAX_RUNS], ev_f[LC3D_MAX_RUNS], ev_r[LC3D_MAX_RUNS], ev_t;   /* side streams: pitch chain, frame-parallel front, frame-parallel tail */
+    hipStream_t s_pre, s_fr; hipEvent_t ev_fork, ev_p[LC3D_MAX_RUNS], ev_f[LC3D_MAX_RUNS];   /* side streams: pitch chain, frame-parallel front, frame-parallel tail */
     int ylen, srow;
     hipStream_t stream, last_stream; hipEvent_t ev0, ev1; float last_ms;
 };
@@ -3019,6 +3016,7 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
     static int split_off = -1;
     if (split_off < 0) { const char* e = getenv("LC3PLUS_ENC_NO_SPLIT"); split_off = e && e[0] == '1'; }
     const bool split = dy12 && ddump && !split_off;
+    float* rows_for_pack = nullptr; const float* frec_for_pack = nullptr;      /* pipelined path: the bitstream writer starts from the shaped spectra (frame-parallel tail, one frame per lane) */
     const int mc = c->big ? LC3D_MEMCAP_BIG : LC3D_MEMCAP_STD;
     if (!split) {
         c->ahead_ok = 0;
@@ -3035,19 +3033,27 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
                                 dout, out_stride, c->ncs, dtr, ddump, dstride, dy12, c->d_status, dT, dt0, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr);
     } else {
         /* The pipelined path.  Per run of frames: on one side stream the pitch chain (resampler per frame, HP50 one stream per lane, OLPA +
-         * LTPF one stream per wave), on another the frame-parallel front (MDCT ... scale factors), the attack decision and the SNS
-         * quantiser (one frame per lane); on the launch stream the rate chain (lc3_enc_seq_kernel), which waits for both.  The side kernels
-         * of run k+1 are resident beside the rate kernel of run k (they were sized for that: lc3_enc_seq.inc). */
-        const size_t ns = (size_t)c->ncs * n_frames * c->srow, nr = (size_t)c->ncs * n_frames * FR_WORDS;
-        if (c->spec_cap < ns) { if (c->d_spec) HIPCHK(hipFree(c->d_spec)); c->d_spec = nullptr; c->spec_cap = 0; HIPCHK(hipMalloc((void**)&c->d_spec, ns * sizeof(float))); c->spec_cap = ns; }
-        if (c->frec_cap < nr) { if (c->d_frec) HIPCHK(hipFree(c->d_frec)); c->d_frec = nullptr; c->frec_cap = 0; HIPCHK(hipMalloc((void**)&c->d_frec, nr * sizeof(float))); c->frec_cap = nr; }
+         * LTPF one stream per wave); on another the frame-parallel front (MDCT ... scale factors), the attack decision and the SNS quantiser
+         * (one frame per lane); on the launch stream the shape kernel (SNS shaping, TNS, log energies: frame-parallel) and behind it the rate
+         * chain (lc3_enc_rate_kernel: rate loop, bisection, first quantisation), which also waits for the pitch chain.  Everything behind the
+         * chain - gain adjustment, second quantisation, noise level, residual - is frame-parallel again and runs one frame per lane at the head
+         * of the bitstream writer, once per call.  The side kernels of run k+1 are resident beside the launch stream's kernels of run k. */
+        /* spectrum rows and records of all dT frames of the call (a call through host pointers comes in pieces: rows dt0 ...): two sets under
+         * the input-ready promise (consecutive calls overlap: the side kernels of a call write one set while the bitstream writer of the call
+         * before still reads the other), one otherwise */
+        const int hb_ = c->input_ready ? c->row_par : 0;
+        const size_t ns = (size_t)c->ncs * dT * c->srow, nr = (size_t)c->ncs * dT * FR_WORDS;
+        if (c->spec_cap[hb_] < ns) { if (c->d_spec[hb_]) HIPCHK(hipFree(c->d_spec[hb_])); c->d_spec[hb_] = nullptr; c->spec_cap[hb_] = 0; HIPCHK(hipMalloc((void**)&c->d_spec[hb_], ns * sizeof(float))); c->spec_cap[hb_] = ns; }
+        if (c->frec_cap[hb_] < nr) { if (c->d_frec[hb_]) HIPCHK(hipFree(c->d_frec[hb_])); c->d_frec[hb_] = nullptr; c->frec_cap[hb_] = 0; HIPCHK(hipMalloc((void**)&c->d_frec[hb_], nr * sizeof(float))); c->frec_cap[hb_] = nr; }
         for (int i = 0; i < 2; i++) if (!c->d_xnext[i]) HIPCHK(hipMalloc((void**)&c->d_xnext[i], (size_t)c->ncs * mc * sizeof(float)));
         if (!c->s_pre) {
             HIPCHK(hipStreamCreateWithFlags(&c->s_pre, hipStreamNonBlocking)); HIPCHK(hipStreamCreateWithFlags(&c->s_fr, hipStreamNonBlocking));
-            HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_t, hipEventDisableTiming));
-            for (int i = 0; i < LC3D_MAX_RUNS; i++) { HIPCHK(hipEventCreateWithFlags(&c->ev_p[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_f[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_s[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_r[i], hipEventDisableTiming)); }
+            HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+            for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming));
+            for (int i = 0; i < LC3D_MAX_RUNS; i++) { HIPCHK(hipEventCreateWithFlags(&c->ev_p[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_f[i], hipEventDisableTiming)); }
         }
-        float* dspec = c->d_spec; float* dfrec = c->d_frec;
+        float* dspec = c->d_spec[hb_]; float* dfrec = c->d_frec[hb_];
+        rows_for_pack = dspec; frec_for_pack = dfrec;
         static int runf = 0;
         if (!runf) { const char* e = getenv("LC3PLUS_ENC_RUN_FRAMES"); runf = e && atoi(e) >= 1 ? atoi(e) : LC3D_RUN_FRAMES; }     /* diagnostic */
         int R = (n_frames + runf - 1) / runf;              /* runs of LC3D_RUN_FRAMES frames */
@@ -3057,13 +3063,10 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
         const int Tr = (n_frames + R - 1) / R;
         /* Where the side kernels of this call may start.  Normally behind everything the caller queued on s before the call (the PCM may
          * come from there).  With lc3hip_set_input_ready - the PCM of a call is complete when the call is made - and a previous call of
-         * the same shape on the same stream, they need not wait for that call's sequential tail and bitstream writer: their streams
-         * carry on in their own order; the kernels of run k wait for the previous call's rate kernel of run k, the last reader of the
-         * hand-over rows they overwrite; the MDCT memory before frame 0 is read from the previous call's hand-over (two alternating
-         * buffers), not from the state that call's last rate kernel is still to update. */
-        /* Measured (bench.py --frames F with / without --serial-calls, Mframes/s): 12 frames 55.9 / 47.2, 16: 56.7 / 51.4, 24: 60.6 / 58.5,
-         * 32: 61.8 / 61.8, 64: 64.6 / 68.2 - a long call loses more to the bitstream writer sharing the chip with the next call's side
-         * kernels than it gains at its ends, so the overlap is taken for calls of up to LC3D_AHEAD_MAX_FRAMES frames. */
+         * the same shape on the same stream, they need not wait for that call's chain and bitstream writer: their streams carry on in
+         * their own order, writing the other set of rows and records (the set they write now was last read by the writer of the call before
+         * the previous one: ev_done); the MDCT memory before frame 0 is read from the previous call's hand-over (two alternating buffers),
+         * not from the state that call's last rate kernel is still to update. */
         static int amax = 0;
         if (!amax) { const char* e = getenv("LC3PLUS_ENC_AHEAD_MAX"); amax = e && atoi(e) >= 1 ? atoi(e) : LC3D_AHEAD_MAX_FRAMES; }     /* diagnostic */
         const bool ahead = c->input_ready && n_frames <= amax && c->ahead_ok && c->ahead_T == n_frames && c->ahead_R == R && c->last_stream == s && dt0 == 0 && dT == n_frames && pack;
@@ -3071,26 +3074,17 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
         const float* xprev = ahead ? c->d_xnext[c->xn_par ^ 1] : c->d_state + LC3D_ST_XPREV;
         const int xprev_stride = ahead ? mc : c->state_words;
         if (!ahead) { HIPCHK(hipEventRecord(c->ev_fork, s)); HIPCHK(hipStreamWaitEvent(c->s_pre, c->ev_fork, 0)); HIPCHK(hipStreamWaitEvent(c->s_fr, c->ev_fork, 0)); }
-        else HIPCHK(hipStreamWaitEvent(c->s_pre, c->ev_f[R - 1], 0));    /* the resampler reads the hand-over the previous call's last front kernel wrote */
+        else {
+            HIPCHK(hipStreamWaitEvent(c->s_pre, c->ev_f[R - 1], 0));    /* the resampler reads the hand-over the previous call's last front kernel wrote */
+            HIPCHK(hipStreamWaitEvent(c->s_pre, c->ev_done[hb_], 0)); HIPCHK(hipStreamWaitEvent(c->s_fr, c->ev_done[hb_], 0));
+        }
         /* The 12.8 kHz pre-kernels run ahead in larger pieces than the runs: the HP50 kernel (one stream per lane, B / 64 waves) costs ~0.1 ms
          * per launch whatever the frame count, which per run would make its stream the slowest.  First piece = the first run (the rate
-         * kernel should start early), then four runs at a time, in stream order between the pitch kernels that need them.  (More side
+         * kernel should start early), then three runs at a time, in stream order between the pitch kernels that need them.  (More side
          * streams than these two do not help: HIP multiplexes streams onto a few hardware queues and kernels of two streams that share
          * one run back to back.) */
-        int run_tb[LC3D_MAX_RUNS], run_nt[LC3D_MAX_RUNS], nruns = 0;
-        static int tfpw = 0;
-        if (!tfpw) { const char* e = getenv("LC3PLUS_ENC_TAIL_FPW"); tfpw = e && atoi(e) >= 1 ? atoi(e) : TAIL_FPW; }     /* diagnostic */
-#define LAUNCH_TAIL(k_) do { const int tb_ = run_tb[k_], nt_ = run_nt[k_]; \
-            const int tpw = nt_ < tfpw ? nt_ : tfpw; const unsigned truns = (unsigned)((nt_ + tpw - 1) / tpw); \
-            HIPCHK(hipStreamWaitEvent(c->s_fr, c->ev_r[k_], 0)); \
-            if (c->big) hipLaunchKernelGGL(lc3_enc_tail_kernel_big, dim3((unsigned)c->ncs * truns), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, n_frames, tb_, nt_, tpw, c->ncs, dspec, c->srow, dfrec, ddump, dstride, dT, dt0, c->d_status); \
-            else DUPL('t') hipLaunchKernelGGL(lc3_enc_tail_kernel, dim3((unsigned)c->ncs * truns), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, n_frames, tb_, nt_, tpw, c->ncs, dspec, c->srow, dfrec, ddump, dstride, dT, dt0, c->d_status); \
-            HIPCHK(hipGetLastError()); \
-            /* the tail kernel is the last reader of the run's rows and records: the next call's side kernels of run k wait for it */ \
-            if (c->input_ready && n_frames <= amax) HIPCHK(hipEventRecord(c->ev_s[k_], c->s_fr)); } while (0)
         for (int k = 0, tb = 0, hb = 0, hk = 0; tb < n_frames; k++, tb += Tr) {
             const int nt = n_frames - tb < Tr ? n_frames - tb : Tr;
-            if (ahead) { HIPCHK(hipStreamWaitEvent(c->s_pre, c->ev_s[k], 0)); HIPCHK(hipStreamWaitEvent(c->s_fr, c->ev_s[k], 0)); }
             if (tb >= hb) {
                 static int prn = 0;
                 if (!prn) { const char* e = getenv("LC3PLUS_ENC_PRE_RUNS"); prn = e && atoi(e) >= 1 ? atoi(e) : 3; }     /* diagnostic */
@@ -3101,20 +3095,19 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
                 HIPCHK(hipGetLastError());
                 hb += hn; hk++;
             }
-            DUPL('p') hipLaunchKernelGGL(lc3_enc_pitch_kernel, dim3(c->ncs), dim3(WAVE), 0, c->s_pre, c->d_plan, c->d_chans, c->d_state, c->state_words, mc, dy12, n_frames, tb, nt, c->ncs, dfrec);
+            DUPL('p') hipLaunchKernelGGL(lc3_enc_pitch_kernel, dim3(c->ncs), dim3(WAVE), 0, c->s_pre, c->d_plan, c->d_chans, c->d_state, c->state_words, mc, dy12, n_frames, tb, nt, c->ncs, dfrec, dT, dt0);
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(c->ev_p[k], c->s_pre));
             const int fpw = nt < FRONT_FPW ? nt : FRONT_FPW;
             const unsigned fruns = (unsigned)((nt + fpw - 1) / fpw);
-            if (c->big) hipLaunchKernelGGL(lc3_enc_front_kernel_big, dim3((unsigned)c->ncs * fruns), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames, tb, nt, fpw, c->ncs, dspec, c->srow, dfrec, xn_w, xprev, xprev_stride);
-            else DUPL('f') hipLaunchKernelGGL(lc3_enc_front_kernel, dim3((unsigned)c->ncs * fruns), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames, tb, nt, fpw, c->ncs, dspec, c->srow, dfrec, xn_w, xprev, xprev_stride);
+            if (c->big) hipLaunchKernelGGL(lc3_enc_front_kernel_big, dim3((unsigned)c->ncs * fruns), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames, tb, nt, fpw, c->ncs, dspec, c->srow, dT, dt0, dfrec, xn_w, xprev, xprev_stride);
+            else DUPL('f') hipLaunchKernelGGL(lc3_enc_front_kernel, dim3((unsigned)c->ncs * fruns), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames, tb, nt, fpw, c->ncs, dspec, c->srow, dT, dt0, dfrec, xn_w, xprev, xprev_stride);
             if (c->any_attack)
-                hipLaunchKernelGGL(lc3_enc_attack_kernel, dim3((unsigned)((c->ncs + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, c->state_words, LC3D_ST_SCAL(mc), dfrec, n_frames, tb, nt, c->ncs);
+                hipLaunchKernelGGL(lc3_enc_attack_kernel, dim3((unsigned)((c->ncs + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, c->state_words, LC3D_ST_SCAL(mc), dfrec, dT, dt0, tb, nt, c->ncs);
             const long long nfr = (long long)c->ncs * nt;
-            DUPL('v') hipLaunchKernelGGL(lc3_enc_snsvq_kernel, dim3((unsigned)((nfr + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->s_fr, c->d_plan, dfrec, n_frames, tb, nt, c->ncs, c->any_attack);
+            DUPL('v') hipLaunchKernelGGL(lc3_enc_snsvq_kernel, dim3((unsigned)((nfr + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->s_fr, c->d_plan, dfrec, dT, dt0, tb, nt, c->ncs, c->any_attack);
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(c->ev_f[k], c->s_fr));
-            if (k >= 2) LAUNCH_TAIL(k - 2);
             HIPCHK(hipStreamWaitEvent(s, c->ev_f[k], 0));
             {   /* shaping, TNS and the stateless half of the gain estimate: frame-parallel, behind the quantiser; on the launch stream in front
                  * of the rate kernel (which is short): the front / quantiser stream and this one then carry about the same load per run */
@@ -3122,24 +3115,17 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
                 if (!sfpw) { const char* e = getenv("LC3PLUS_ENC_SHAPE_FPW"); sfpw = e && atoi(e) >= 1 ? atoi(e) : SHAPE_FPW; }     /* diagnostic */
                 const int spw = nt < sfpw ? nt : sfpw;
                 const unsigned sruns = (unsigned)((nt + spw - 1) / spw);
-                if (c->big) hipLaunchKernelGGL(lc3_enc_shape_kernel_big, dim3((unsigned)c->ncs * sruns), dim3(WAVE), 0, s, c->d_plan, c->d_chans, n_frames, tb, nt, spw, c->ncs, dspec, c->srow, dfrec);
-                else DUPL('a') hipLaunchKernelGGL(lc3_enc_shape_kernel, dim3((unsigned)c->ncs * sruns), dim3(WAVE), 0, s, c->d_plan, c->d_chans, n_frames, tb, nt, spw, c->ncs, dspec, c->srow, dfrec);
+                if (c->big) hipLaunchKernelGGL(lc3_enc_shape_kernel_big, dim3((unsigned)c->ncs * sruns), dim3(WAVE), 0, s, c->d_plan, c->d_chans, dT, dt0 + tb, nt, spw, c->ncs, dspec, c->srow, dfrec);
+                else DUPL('a') hipLaunchKernelGGL(lc3_enc_shape_kernel, dim3((unsigned)c->ncs * sruns), dim3(WAVE), 0, s, c->d_plan, c->d_chans, dT, dt0 + tb, nt, spw, c->ncs, dspec, c->srow, dfrec);
             }
             HIPCHK(hipStreamWaitEvent(s, c->ev_p[k], 0));
-            if (c->big) hipLaunchKernelGGL(lc3_enc_rate_kernel_big, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, n_frames, tb, nt, c->ncs, dspec, c->srow, dfrec, xn_w);
-            else DUPL('s') hipLaunchKernelGGL(lc3_enc_rate_kernel, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, n_frames, tb, nt, c->ncs, dspec, c->srow, dfrec, xn_w);
+            const int last = tb + nt >= n_frames;            /* behind the last frame of this launch the MDCT memory goes into the state */
+            if (c->big) hipLaunchKernelGGL(lc3_enc_rate_kernel_big, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, dT, dt0 + tb, nt, c->ncs, dspec, c->srow, dfrec, xn_w, last);
+            else DUPL('s') hipLaunchKernelGGL(lc3_enc_rate_kernel, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, dT, dt0 + tb, nt, c->ncs, dspec, c->srow, dfrec, xn_w, last);
             HIPCHK(hipGetLastError());
-            HIPCHK(hipEventRecord(c->ev_r[k], s));
-            run_tb[k] = tb; run_nt[k] = nt; nruns = k + 1;
         }
-        /* behind the chain, frame-parallel again: gain adjustment, second quantisation, noise level, residual, pack record.  On the front's stream,
-         * two runs late, so that its wait for the rate kernel never holds that stream up (HIP maps streams onto a few hardware queues: a side
-         * stream of its own shared one with the front's and stalled it at every wait) */
-        for (int k = nruns < 2 ? 0 : nruns - 2; k < nruns; k++) LAUNCH_TAIL(k);
-        HIPCHK(hipEventRecord(c->ev_t, c->s_fr));
-        HIPCHK(hipStreamWaitEvent(s, c->ev_t, 0));       /* everything of the call is behind s again */
-#undef LAUNCH_TAIL
-        c->ahead_ok = (dt0 == 0 && dT == n_frames && pack) ? 1 : 0; c->ahead_T = n_frames; c->ahead_R = R; c->xn_par ^= 1;
+        c->ahead_ok = (dt0 == 0 && dT == n_frames && pack) ? 1 : 0; c->ahead_T = n_frames; c->ahead_R = R;
+        c->xn_par ^= 1;
     }
     if (ddump && pack) {
         HIPCHK(hipGetLastError());
@@ -3147,7 +3133,8 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
         const size_t per_wave = (size_t)PK_XBUF * WAVE * sizeof(unsigned);
         const long long tasks = (long long)c->ncs * dT, per_wg = (long long)wpg * WAVE;
         DUPL('k') hipLaunchKernelGGL(lc3_enc_pack_kernel, dim3((unsigned)((tasks + per_wg - 1) / per_wg)), dim3(wpg * WAVE), per_wave * wpg, s, c->d_plan, c->d_chans, ddump, dstride,
-                           dT, 0, dT, c->ncs, dout, out_stride, c->d_status);
+                           dT, 0, dT, c->ncs, dout, out_stride, c->d_status, rows_for_pack, c->srow, frec_for_pack);
+        if (split && c->input_ready) { HIPCHK(hipEventRecord(c->ev_done[c->row_par], s)); c->row_par ^= 1; }      /* this call's set of rows and records is free again */
     }
     HIPCHK(hipGetLastError());
     c->last_stream = s;
@@ -3321,8 +3308,7 @@ extern "C" int lc3hip_destroy(void* ctx)
     if (c->d_y12) hipFree(c->d_y12);
     if (c->d_trace) hipFree(c->d_trace);
     if (c->d_status) hipFree(c->d_status);
-    if (c->d_spec) hipFree(c->d_spec);
-    if (c->d_frec) hipFree(c->d_frec);
+    for (int i = 0; i < 2; i++) { if (c->d_spec[i]) hipFree(c->d_spec[i]); if (c->d_frec[i]) hipFree(c->d_frec[i]); }
     for (int i = 0; i < 2; i++) if (c->d_xnext[i]) hipFree(c->d_xnext[i]);
     free(c->h_attack);
     for (int i = 0; i < 2; i++) {
@@ -3332,8 +3318,8 @@ extern "C" int lc3hip_destroy(void* ctx)
         if (c->ev_k[i]) hipEventDestroy(c->ev_k[i]);
     }
     if (c->s_h2d) hipStreamDestroy(c->s_h2d);
-    if (c->s_pre) { hipStreamDestroy(c->s_pre); hipStreamDestroy(c->s_fr); hipEventDestroy(c->ev_fork); hipEventDestroy(c->ev_t);
-                    for (int i = 0; i < LC3D_MAX_RUNS; i++) { hipEventDestroy(c->ev_p[i]); hipEventDestroy(c->ev_f[i]); hipEventDestroy(c->ev_s[i]); hipEventDestroy(c->ev_r[i]); } }
+    if (c->s_pre) { hipStreamDestroy(c->s_pre); hipStreamDestroy(c->s_fr); hipEventDestroy(c->ev_fork); hipEventDestroy(c->ev_done[0]); hipEventDestroy(c->ev_done[1]);
+                    for (int i = 0; i < LC3D_MAX_RUNS; i++) { hipEventDestroy(c->ev_p[i]); hipEventDestroy(c->ev_f[i]); } }
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
     if (c->stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); }
