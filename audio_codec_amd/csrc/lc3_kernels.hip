@@ -2883,6 +2883,7 @@ extern "C" __global__ void lc3_enc_rate_kernel_big(const lc3d_plan* __restrict__
                                                    const float* __restrict__ rows, int srow, float* __restrict__ frec, const float* __restrict__ xnext, int last);
 #include "lc3_enc_pack.inc"
 #include "lc3_enc_snsvq.inc"
+#include "lc3_enc_shapel.inc"
 #include "lc3_enc_pre.inc"
 #define LC3D_MAX_RUNS 16
 #define LC3D_AHEAD_MAX_FRAMES 40      /* lc3hip_set_input_ready: calls of up to this many frames overlap with their predecessor */
@@ -3106,17 +3107,22 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
                 hipLaunchKernelGGL(lc3_enc_attack_kernel, dim3((unsigned)((c->ncs + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, c->state_words, LC3D_ST_SCAL(mc), dfrec, dT, dt0, tb, nt, c->ncs);
             const long long nfr = (long long)c->ncs * nt;
             DUPL('v') hipLaunchKernelGGL(lc3_enc_snsvq_kernel, dim3((unsigned)((nfr + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->s_fr, c->d_plan, dfrec, dT, dt0, tb, nt, c->ncs, c->any_attack);
-            HIPCHK(hipGetLastError());
-            HIPCHK(hipEventRecord(c->ev_f[k], c->s_fr));
-            HIPCHK(hipStreamWaitEvent(s, c->ev_f[k], 0));
-            {   /* shaping, TNS and the stateless half of the gain estimate: frame-parallel, behind the quantiser; on the launch stream in front
-                 * of the rate kernel (which is short): the front / quantiser stream and this one then carry about the same load per run */
-                static int sfpw = 0;
+            {   /* shaping, TNS and the stateless half of the gain estimate: frame-parallel, behind the quantiser (LC3PLUS_ENC_SHAPE_ON_S=1, diagnostic: on the
+                 * launch stream in front of the rate kernel instead) */
+                static int sfpw = 0, son = -1;
                 if (!sfpw) { const char* e = getenv("LC3PLUS_ENC_SHAPE_FPW"); sfpw = e && atoi(e) >= 1 ? atoi(e) : SHAPE_FPW; }     /* diagnostic */
+                if (son < 0) { const char* e = getenv("LC3PLUS_ENC_SHAPE_ON_S"); son = e && e[0] == '1'; }
                 const int spw = nt < sfpw ? nt : sfpw;
                 const unsigned sruns = (unsigned)((nt + spw - 1) / spw);
-                if (c->big) hipLaunchKernelGGL(lc3_enc_shape_kernel_big, dim3((unsigned)c->ncs * sruns), dim3(WAVE), 0, s, c->d_plan, c->d_chans, dT, dt0 + tb, nt, spw, c->ncs, dspec, c->srow, dfrec);
-                else DUPL('a') hipLaunchKernelGGL(lc3_enc_shape_kernel, dim3((unsigned)c->ncs * sruns), dim3(WAVE), 0, s, c->d_plan, c->d_chans, dT, dt0 + tb, nt, spw, c->ncs, dspec, c->srow, dfrec);
+                hipStream_t ss = son ? s : c->s_fr;
+                if (son) { HIPCHK(hipEventRecord(c->ev_f[k], c->s_fr)); HIPCHK(hipStreamWaitEvent(s, c->ev_f[k], 0)); }
+                static int swave = -1;
+                if (swave < 0) { const char* e = getenv("LC3PLUS_ENC_SHAPE_WAVE"); swave = e && e[0] == '1'; }     /* diagnostic: the wave-per-frame kernel */
+                if (c->big) hipLaunchKernelGGL(lc3_enc_shape_kernel_big, dim3((unsigned)c->ncs * sruns), dim3(WAVE), 0, ss, c->d_plan, c->d_chans, dT, dt0 + tb, nt, spw, c->ncs, dspec, c->srow, dfrec);
+                else if (!swave) DUPL('a') hipLaunchKernelGGL(lc3_enc_shape_lane_kernel, dim3((unsigned)(((long long)c->ncs * nt + WAVE - 1) / WAVE)), dim3(WAVE), 0, ss, c->d_plan, c->d_chans, dT, dt0 + tb, nt, c->ncs, dspec, c->srow, dfrec);
+                else DUPL('a') hipLaunchKernelGGL(lc3_enc_shape_kernel, dim3((unsigned)c->ncs * sruns), dim3(WAVE), 0, ss, c->d_plan, c->d_chans, dT, dt0 + tb, nt, spw, c->ncs, dspec, c->srow, dfrec);
+                HIPCHK(hipGetLastError());
+                if (!son) { HIPCHK(hipEventRecord(c->ev_f[k], c->s_fr)); HIPCHK(hipStreamWaitEvent(s, c->ev_f[k], 0)); }
             }
             HIPCHK(hipStreamWaitEvent(s, c->ev_p[k], 0));
             const int last = tb + nt >= n_frames;            /* behind the last frame of this launch the MDCT memory goes into the state */
