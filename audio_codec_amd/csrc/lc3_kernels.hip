@@ -2876,7 +2876,7 @@ extern "C" __global__ void lc3_encode_kernel_big(const lc3d_plan* __restrict__ P
                                                  uint8_t* __restrict__ status, int dT, int dt0, const float* __restrict__ spec, const float* __restrict__ frec,
                                                  const float* __restrict__ xnext);
 extern "C" __global__ void lc3_enc_front_kernel_big(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans, const float* __restrict__ state, const void* __restrict__ pcm,
-                                                    int bitdepth, int T, int tb, int nt, int fpw, int ncs, float* __restrict__ spec, int srow, int RT, int r0, float* __restrict__ rec, float* __restrict__ xnext, const float* __restrict__ xprev, int xprev_stride);
+                                                    int bitdepth, int T, int tb, int nt, int fpw, int ncs, float* __restrict__ spec, int srow, int RT, int r0, float* __restrict__ rec, float* __restrict__ xnext, const float* __restrict__ xprev, int xprev_stride, int do_scf);
 extern "C" __global__ void lc3_enc_shape_kernel_big(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans, int T, int tb, int nt, int fpw, int ncs,
                                                     float* __restrict__ rows, int srow, float* __restrict__ frec);
 extern "C" __global__ void lc3_enc_rate_kernel_big(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans, float* __restrict__ state, int T, int t0, int nt, int ncs,
@@ -2886,8 +2886,9 @@ extern "C" __global__ void lc3_enc_rate_kernel_big(const lc3d_plan* __restrict__
 #include "lc3_enc_shapel.inc"
 #include "lc3_enc_pre.inc"
 #define LC3D_MAX_RUNS 16
-#define LC3D_AHEAD_MAX_FRAMES 40      /* lc3hip_set_input_ready: calls of up to this many frames overlap with their predecessor */
-#define LC3D_RUN_FRAMES 8
+#define LC3D_AHEAD_MAX_FRAMES 256     /* lc3hip_set_input_ready: calls of up to this many frames overlap with their predecessor */
+#define LC3D_RUN_FRAMES 16            /* frames per run when consecutive calls do not overlap (measured, 4096 streams x 64 frames: 8: 58.1, 16: 64.9, 32: 62.8, 64: 58.6 Mframes/s) */
+#define LC3D_RUN_FRAMES_READY 64      /* under the input-ready promise (calls overlap, a call's own pipeline matters less: 8: 62.4, 16: 70.1, 32: 72.6, 64: 73.0) */
 struct lc3hip_ctx {
     int device, ncs, n_streams, channels, N, big, state_words;
     lc3d_plan* d_plan; lc3d_chan* d_chans; float* d_state;
@@ -3055,9 +3056,10 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
         }
         float* dspec = c->d_spec[hb_]; float* dfrec = c->d_frec[hb_];
         rows_for_pack = dspec; frec_for_pack = dfrec;
-        static int runf = 0;
-        if (!runf) { const char* e = getenv("LC3PLUS_ENC_RUN_FRAMES"); runf = e && atoi(e) >= 1 ? atoi(e) : LC3D_RUN_FRAMES; }     /* diagnostic */
-        int R = (n_frames + runf - 1) / runf;              /* runs of LC3D_RUN_FRAMES frames */
+        static int runf_env = -1;
+        if (runf_env < 0) { const char* e = getenv("LC3PLUS_ENC_RUN_FRAMES"); runf_env = e && atoi(e) >= 1 ? atoi(e) : 0; }     /* diagnostic */
+        const int runf = runf_env ? runf_env : c->input_ready ? LC3D_RUN_FRAMES_READY : LC3D_RUN_FRAMES;
+        int R = (n_frames + runf - 1) / runf;              /* runs of frames */
         if (R > LC3D_MAX_RUNS) R = LC3D_MAX_RUNS;
         if (R < 1) R = 1;
         { const char* e = getenv("LC3PLUS_ENC_RUNS"); if (e && atoi(e) >= 1 && atoi(e) <= LC3D_MAX_RUNS) R = atoi(e); }     /* diagnostic */
@@ -3099,10 +3101,13 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
             DUPL('p') hipLaunchKernelGGL(lc3_enc_pitch_kernel, dim3(c->ncs), dim3(WAVE), 0, c->s_pre, c->d_plan, c->d_chans, c->d_state, c->state_words, mc, dy12, n_frames, tb, nt, c->ncs, dfrec, dT, dt0);
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(c->ev_p[k], c->s_pre));
+            static int scf_wave = -1;
+            if (scf_wave < 0) { const char* e = getenv("LC3PLUS_ENC_SCF_WAVE"); scf_wave = e && e[0] == '1'; }     /* diagnostic: energies / scale factors in the front kernel */
             const int fpw = nt < FRONT_FPW ? nt : FRONT_FPW;
             const unsigned fruns = (unsigned)((nt + fpw - 1) / fpw);
-            if (c->big) hipLaunchKernelGGL(lc3_enc_front_kernel_big, dim3((unsigned)c->ncs * fruns), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames, tb, nt, fpw, c->ncs, dspec, c->srow, dT, dt0, dfrec, xn_w, xprev, xprev_stride);
-            else DUPL('f') hipLaunchKernelGGL(lc3_enc_front_kernel, dim3((unsigned)c->ncs * fruns), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames, tb, nt, fpw, c->ncs, dspec, c->srow, dT, dt0, dfrec, xn_w, xprev, xprev_stride);
+            if (c->big) hipLaunchKernelGGL(lc3_enc_front_kernel_big, dim3((unsigned)c->ncs * fruns), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames, tb, nt, fpw, c->ncs, dspec, c->srow, dT, dt0, dfrec, xn_w, xprev, xprev_stride, 1);
+            else DUPL('f') hipLaunchKernelGGL(lc3_enc_front_kernel, dim3((unsigned)c->ncs * fruns), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames, tb, nt, fpw, c->ncs, dspec, c->srow, dT, dt0, dfrec, xn_w, xprev, xprev_stride, scf_wave);
+            if (!c->big && !scf_wave) DUPL('e') hipLaunchKernelGGL(lc3_enc_scf_lane_kernel, dim3((unsigned)(((long long)c->ncs * nt + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->s_fr, c->d_plan, dT, dt0 + tb, nt, c->ncs, dspec, c->srow, dfrec);
             if (c->any_attack)
                 hipLaunchKernelGGL(lc3_enc_attack_kernel, dim3((unsigned)((c->ncs + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, c->state_words, LC3D_ST_SCAL(mc), dfrec, dT, dt0, tb, nt, c->ncs);
             const long long nfr = (long long)c->ncs * nt;
