@@ -2886,6 +2886,7 @@ extern "C" __global__ void lc3_enc_rate_kernel_big(const lc3d_plan* __restrict__
 #include "lc3_enc_shapel.inc"
 #include "lc3_enc_pre.inc"
 #define LC3D_MAX_RUNS 16
+#define LC3D_SETS 3                     /* sets of hand-over buffers under the input-ready promise: that many calls may be in flight */
 #define LC3D_AHEAD_MAX_FRAMES 256     /* lc3hip_set_input_ready: calls of up to this many frames overlap with their predecessor */
 #define LC3D_RUN_FRAMES 16            /* frames per run when consecutive calls do not overlap (measured, 4096 streams x 64 frames: 8: 58.1, 16: 64.9, 32: 62.8, 64: 58.6 Mframes/s) */
 #define LC3D_RUN_FRAMES_READY 64      /* under the input-ready promise (calls overlap, a call's own pipeline matters less: 8: 62.4, 16: 70.1, 32: 72.6, 64: 73.0) */
@@ -2894,14 +2895,14 @@ struct lc3hip_ctx {
     lc3d_plan* d_plan; lc3d_chan* d_chans; float* d_state;
     void* d_pcm; size_t pcm_cap; uint8_t* d_out; size_t out_cap;
     lc3d_trace* d_trace; size_t trace_cap;
-    int* d_dump; size_t dump_cap; int hr, fused; float* d_y12; size_t y12_cap;
+    int* d_dump; size_t dump_cap; int hr, fused; float* d_y12[LC3D_SETS]; size_t y12_cap[LC3D_SETS];
     uint8_t* d_status; size_t status_cap; int status_frames;
-    float* d_spec[2]; size_t spec_cap[2]; float* d_frec[2]; size_t frec_cap[2]; hipEvent_t ev_done[2]; float* d_xnext[2]; int xn_par, row_par; uint8_t* h_attack; int any_attack;
+    float* d_spec[LC3D_SETS]; size_t spec_cap[LC3D_SETS]; float* d_frec[LC3D_SETS]; size_t frec_cap[LC3D_SETS]; hipEvent_t ev_done[LC3D_SETS]; float* d_xnext[LC3D_SETS + 1]; int xn_par, row_par; uint8_t* h_attack; int any_attack;
     int input_ready, ahead_ok, ahead_T, ahead_R;   /* lc3hip_set_input_ready: side kernels of a call beside the previous call's tail */   /* split path (lc3_enc_front.inc) */      /* per channel-frame status bits of the last call (LC3D_ENC_ST_*) */
     /* host-pointer pipeline (lc3hip_encode_host): two chunk slots, each with device staging and (for pageable callers) pinned staging */
     void* hp_dpcm[2]; void* hp_pin_in[2]; size_t hp_pcm_cap, hp_pin_in_cap;
     hipStream_t s_h2d; hipEvent_t ev_h2d[2], ev_k[2];
-    hipStream_t s_pre, s_fr; hipEvent_t ev_fork, ev_p[LC3D_MAX_RUNS], ev_f[LC3D_MAX_RUNS];   /* side streams: pitch chain, frame-parallel front, frame-parallel tail */
+    hipStream_t s_pre, s_fr, s_pit, s_ln; hipEvent_t ev_fork, ev_p[LC3D_MAX_RUNS], ev_f[LC3D_MAX_RUNS], ev_h[LC3D_MAX_RUNS], ev_m[LC3D_MAX_RUNS];   /* side streams: pitch chain, frame-parallel front, frame-parallel tail */
     int ylen, srow;
     hipStream_t stream, last_stream; hipEvent_t ev0, ev1; float last_ms;
 };
@@ -3006,8 +3007,9 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
     float* dy12 = nullptr;
     if (!dtr && !c->fused) {
         const size_t need = (size_t)c->ncs * n_frames * 128;
-        if (c->y12_cap < need) { if (c->d_y12) HIPCHK(hipFree(c->d_y12)); c->d_y12 = nullptr; c->y12_cap = 0; HIPCHK(hipMalloc((void**)&c->d_y12, need * sizeof(float))); c->y12_cap = need; }
-        dy12 = c->d_y12;
+        const int yb = c->input_ready ? c->row_par : 0;      /* two buffers under the input-ready promise: the next call's resampler may run beside this call's pitch kernel */
+        if (c->y12_cap[yb] < need) { if (c->d_y12[yb]) HIPCHK(hipFree(c->d_y12[yb])); c->d_y12[yb] = nullptr; c->y12_cap[yb] = 0; HIPCHK(hipMalloc((void**)&c->d_y12[yb], need * sizeof(float))); c->y12_cap[yb] = need; }
+        dy12 = c->d_y12[yb];
     }
     if (dt0 == 0) {   /* per channel-frame status bits (LC3D_ENC_ST_*), cleared per call */
         const size_t need = (size_t)c->ncs * dT;
@@ -3047,11 +3049,16 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
         const size_t ns = (size_t)c->ncs * dT * c->srow, nr = (size_t)c->ncs * dT * FR_WORDS;
         if (c->spec_cap[hb_] < ns) { if (c->d_spec[hb_]) HIPCHK(hipFree(c->d_spec[hb_])); c->d_spec[hb_] = nullptr; c->spec_cap[hb_] = 0; HIPCHK(hipMalloc((void**)&c->d_spec[hb_], ns * sizeof(float))); c->spec_cap[hb_] = ns; }
         if (c->frec_cap[hb_] < nr) { if (c->d_frec[hb_]) HIPCHK(hipFree(c->d_frec[hb_])); c->d_frec[hb_] = nullptr; c->frec_cap[hb_] = 0; HIPCHK(hipMalloc((void**)&c->d_frec[hb_], nr * sizeof(float))); c->frec_cap[hb_] = nr; }
-        for (int i = 0; i < 2; i++) if (!c->d_xnext[i]) HIPCHK(hipMalloc((void**)&c->d_xnext[i], (size_t)c->ncs * mc * sizeof(float)));
+        for (int i = 0; i < LC3D_SETS + 1; i++) if (!c->d_xnext[i]) HIPCHK(hipMalloc((void**)&c->d_xnext[i], (size_t)c->ncs * mc * sizeof(float)));
         if (!c->s_pre) {
             HIPCHK(hipStreamCreateWithFlags(&c->s_pre, hipStreamNonBlocking)); HIPCHK(hipStreamCreateWithFlags(&c->s_fr, hipStreamNonBlocking));
+            /* LC3PLUS_ENC_STREAMS=5: the pitch kernel and the one-frame-per-lane kernels on streams of their own (pays only where the HIP runtime has
+             * hardware queues for them: GPU_MAX_HW_QUEUES >= 6) */
+            { const char* e = getenv("LC3PLUS_ENC_STREAMS"); c->s_pit = c->s_pre; c->s_ln = c->s_fr;
+              if (e && atoi(e) >= 5) { HIPCHK(hipStreamCreateWithFlags(&c->s_pit, hipStreamNonBlocking)); HIPCHK(hipStreamCreateWithFlags(&c->s_ln, hipStreamNonBlocking)); } }
+            for (int i = 0; i < LC3D_MAX_RUNS; i++) { HIPCHK(hipEventCreateWithFlags(&c->ev_h[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_m[i], hipEventDisableTiming)); }
             HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-            for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming));
+            for (int i = 0; i < LC3D_SETS; i++) HIPCHK(hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming));
             for (int i = 0; i < LC3D_MAX_RUNS; i++) { HIPCHK(hipEventCreateWithFlags(&c->ev_p[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_f[i], hipEventDisableTiming)); }
         }
         float* dspec = c->d_spec[hb_]; float* dfrec = c->d_frec[hb_];
@@ -3074,12 +3081,19 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
         if (!amax) { const char* e = getenv("LC3PLUS_ENC_AHEAD_MAX"); amax = e && atoi(e) >= 1 ? atoi(e) : LC3D_AHEAD_MAX_FRAMES; }     /* diagnostic */
         const bool ahead = c->input_ready && n_frames <= amax && c->ahead_ok && c->ahead_T == n_frames && c->ahead_R == R && c->last_stream == s && dt0 == 0 && dT == n_frames && pack;
         float* xn_w = c->d_xnext[c->xn_par];                         /* written by this call's front kernel */
-        const float* xprev = ahead ? c->d_xnext[c->xn_par ^ 1] : c->d_state + LC3D_ST_XPREV;
+        /* one buffer more than calls in flight: the one written now was last read by the call LC3D_SETS back (its resampler and front) and by the
+         * rate kernel of the call before that, all finished before the bitstream writer this call's side streams have waited for */
+        const float* xprev = ahead ? c->d_xnext[(c->xn_par + LC3D_SETS) % (LC3D_SETS + 1)] : c->d_state + LC3D_ST_XPREV;
         const int xprev_stride = ahead ? mc : c->state_words;
-        if (!ahead) { HIPCHK(hipEventRecord(c->ev_fork, s)); HIPCHK(hipStreamWaitEvent(c->s_pre, c->ev_fork, 0)); HIPCHK(hipStreamWaitEvent(c->s_fr, c->ev_fork, 0)); }
-        else {
-            HIPCHK(hipStreamWaitEvent(c->s_pre, c->ev_f[R - 1], 0));    /* the resampler reads the hand-over the previous call's last front kernel wrote */
+        const bool five = c->s_pit != c->s_pre;
+        if (!ahead) {
+            HIPCHK(hipEventRecord(c->ev_fork, s)); HIPCHK(hipStreamWaitEvent(c->s_pre, c->ev_fork, 0)); HIPCHK(hipStreamWaitEvent(c->s_fr, c->ev_fork, 0));
+            if (five) { HIPCHK(hipStreamWaitEvent(c->s_pit, c->ev_fork, 0)); HIPCHK(hipStreamWaitEvent(c->s_ln, c->ev_fork, 0)); }
+        } else {
+            HIPCHK(hipStreamWaitEvent(c->s_pre, c->ev_m[R - 1], 0));    /* the resampler reads the hand-over the previous call's last front kernel wrote */
             HIPCHK(hipStreamWaitEvent(c->s_pre, c->ev_done[hb_], 0)); HIPCHK(hipStreamWaitEvent(c->s_fr, c->ev_done[hb_], 0));
+            if (five) { HIPCHK(hipStreamWaitEvent(c->s_pit, c->ev_done[hb_], 0)); HIPCHK(hipStreamWaitEvent(c->s_ln, c->ev_done[hb_], 0));
+                        if (c->any_attack) HIPCHK(hipStreamWaitEvent(c->s_fr, c->ev_f[R - 1], 0)); }      /* the front reads the attack detector's filter memory the previous call's attack kernel leaves */
         }
         /* The 12.8 kHz pre-kernels run ahead in larger pieces than the runs: the HP50 kernel (one stream per lane, B / 64 waves) costs ~0.1 ms
          * per launch whatever the frame count, which per run would make its stream the slowest.  First piece = the first run (the rate
@@ -3097,21 +3111,24 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
                 DUPL('h') hipLaunchKernelGGL(lc3_enc_hp50_kernel, dim3((unsigned)((c->ncs + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->s_pre, c->d_plan, c->d_state, c->state_words, LC3D_ST_SCAL(mc), n_frames, hb, hn, c->ncs, dy12);
                 HIPCHK(hipGetLastError());
                 hb += hn; hk++;
+                if (five) { HIPCHK(hipEventRecord(c->ev_h[k], c->s_pre)); HIPCHK(hipStreamWaitEvent(c->s_pit, c->ev_h[k], 0)); }
             }
-            DUPL('p') hipLaunchKernelGGL(lc3_enc_pitch_kernel, dim3(c->ncs), dim3(WAVE), 0, c->s_pre, c->d_plan, c->d_chans, c->d_state, c->state_words, mc, dy12, n_frames, tb, nt, c->ncs, dfrec, dT, dt0);
+            DUPL('p') hipLaunchKernelGGL(lc3_enc_pitch_kernel, dim3(c->ncs), dim3(WAVE), 0, c->s_pit, c->d_plan, c->d_chans, c->d_state, c->state_words, mc, dy12, n_frames, tb, nt, c->ncs, dfrec, dT, dt0);
             HIPCHK(hipGetLastError());
-            HIPCHK(hipEventRecord(c->ev_p[k], c->s_pre));
+            HIPCHK(hipEventRecord(c->ev_p[k], c->s_pit));
             static int scf_wave = -1;
             if (scf_wave < 0) { const char* e = getenv("LC3PLUS_ENC_SCF_WAVE"); scf_wave = e && e[0] == '1'; }     /* diagnostic: energies / scale factors in the front kernel */
             const int fpw = nt < FRONT_FPW ? nt : FRONT_FPW;
             const unsigned fruns = (unsigned)((nt + fpw - 1) / fpw);
             if (c->big) hipLaunchKernelGGL(lc3_enc_front_kernel_big, dim3((unsigned)c->ncs * fruns), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames, tb, nt, fpw, c->ncs, dspec, c->srow, dT, dt0, dfrec, xn_w, xprev, xprev_stride, 1);
             else DUPL('f') hipLaunchKernelGGL(lc3_enc_front_kernel, dim3((unsigned)c->ncs * fruns), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames, tb, nt, fpw, c->ncs, dspec, c->srow, dT, dt0, dfrec, xn_w, xprev, xprev_stride, scf_wave);
-            if (!c->big && !scf_wave) DUPL('e') hipLaunchKernelGGL(lc3_enc_scf_lane_kernel, dim3((unsigned)(((long long)c->ncs * nt + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->s_fr, c->d_plan, dT, dt0 + tb, nt, c->ncs, dspec, c->srow, dfrec);
+            HIPCHK(hipEventRecord(c->ev_m[k], c->s_fr));                 /* the MDCT memory hand-over and the spectrum rows of the run are written */
+            if (five) HIPCHK(hipStreamWaitEvent(c->s_ln, c->ev_m[k], 0));
+            if (!c->big && !scf_wave) DUPL('e') hipLaunchKernelGGL(lc3_enc_scf_lane_kernel, dim3((unsigned)(((long long)c->ncs * nt + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->s_ln, c->d_plan, dT, dt0 + tb, nt, c->ncs, dspec, c->srow, dfrec);
             if (c->any_attack)
-                hipLaunchKernelGGL(lc3_enc_attack_kernel, dim3((unsigned)((c->ncs + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, c->state_words, LC3D_ST_SCAL(mc), dfrec, dT, dt0, tb, nt, c->ncs);
+                hipLaunchKernelGGL(lc3_enc_attack_kernel, dim3((unsigned)((c->ncs + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->s_ln, c->d_plan, c->d_chans, c->d_state, c->state_words, LC3D_ST_SCAL(mc), dfrec, dT, dt0, tb, nt, c->ncs);
             const long long nfr = (long long)c->ncs * nt;
-            DUPL('v') hipLaunchKernelGGL(lc3_enc_snsvq_kernel, dim3((unsigned)((nfr + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->s_fr, c->d_plan, dfrec, dT, dt0, tb, nt, c->ncs, c->any_attack);
+            DUPL('v') hipLaunchKernelGGL(lc3_enc_snsvq_kernel, dim3((unsigned)((nfr + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->s_ln, c->d_plan, dfrec, dT, dt0, tb, nt, c->ncs, c->any_attack);
             {   /* shaping, TNS and the stateless half of the gain estimate: frame-parallel, behind the quantiser (LC3PLUS_ENC_SHAPE_ON_S=1, diagnostic: on the
                  * launch stream in front of the rate kernel instead) */
                 static int sfpw = 0, son = -1;
@@ -3119,15 +3136,15 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
                 if (son < 0) { const char* e = getenv("LC3PLUS_ENC_SHAPE_ON_S"); son = e && e[0] == '1'; }
                 const int spw = nt < sfpw ? nt : sfpw;
                 const unsigned sruns = (unsigned)((nt + spw - 1) / spw);
-                hipStream_t ss = son ? s : c->s_fr;
-                if (son) { HIPCHK(hipEventRecord(c->ev_f[k], c->s_fr)); HIPCHK(hipStreamWaitEvent(s, c->ev_f[k], 0)); }
+                hipStream_t ss = son ? s : c->s_ln;
+                if (son) { HIPCHK(hipEventRecord(c->ev_f[k], c->s_ln)); HIPCHK(hipStreamWaitEvent(s, c->ev_f[k], 0)); }
                 static int swave = -1;
                 if (swave < 0) { const char* e = getenv("LC3PLUS_ENC_SHAPE_WAVE"); swave = e && e[0] == '1'; }     /* diagnostic: the wave-per-frame kernel */
                 if (c->big) hipLaunchKernelGGL(lc3_enc_shape_kernel_big, dim3((unsigned)c->ncs * sruns), dim3(WAVE), 0, ss, c->d_plan, c->d_chans, dT, dt0 + tb, nt, spw, c->ncs, dspec, c->srow, dfrec);
                 else if (!swave) DUPL('a') hipLaunchKernelGGL(lc3_enc_shape_lane_kernel, dim3((unsigned)(((long long)c->ncs * nt + WAVE - 1) / WAVE)), dim3(WAVE), 0, ss, c->d_plan, c->d_chans, dT, dt0 + tb, nt, c->ncs, dspec, c->srow, dfrec);
                 else DUPL('a') hipLaunchKernelGGL(lc3_enc_shape_kernel, dim3((unsigned)c->ncs * sruns), dim3(WAVE), 0, ss, c->d_plan, c->d_chans, dT, dt0 + tb, nt, spw, c->ncs, dspec, c->srow, dfrec);
                 HIPCHK(hipGetLastError());
-                if (!son) { HIPCHK(hipEventRecord(c->ev_f[k], c->s_fr)); HIPCHK(hipStreamWaitEvent(s, c->ev_f[k], 0)); }
+                if (!son) { HIPCHK(hipEventRecord(c->ev_f[k], c->s_ln)); HIPCHK(hipStreamWaitEvent(s, c->ev_f[k], 0)); }
             }
             HIPCHK(hipStreamWaitEvent(s, c->ev_p[k], 0));
             const int last = tb + nt >= n_frames;            /* behind the last frame of this launch the MDCT memory goes into the state */
@@ -3136,7 +3153,7 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
             HIPCHK(hipGetLastError());
         }
         c->ahead_ok = (dt0 == 0 && dT == n_frames && pack) ? 1 : 0; c->ahead_T = n_frames; c->ahead_R = R;
-        c->xn_par ^= 1;
+        c->xn_par = (c->xn_par + 1) % (LC3D_SETS + 1);
     }
     if (ddump && pack) {
         HIPCHK(hipGetLastError());
@@ -3145,7 +3162,7 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
         const long long tasks = (long long)c->ncs * dT, per_wg = (long long)wpg * WAVE;
         DUPL('k') hipLaunchKernelGGL(lc3_enc_pack_kernel, dim3((unsigned)((tasks + per_wg - 1) / per_wg)), dim3(wpg * WAVE), per_wave * wpg, s, c->d_plan, c->d_chans, ddump, dstride,
                            dT, 0, dT, c->ncs, dout, out_stride, c->d_status, rows_for_pack, c->srow, frec_for_pack);
-        if (split && c->input_ready) { HIPCHK(hipEventRecord(c->ev_done[c->row_par], s)); c->row_par ^= 1; }      /* this call's set of rows and records is free again */
+        if (split && c->input_ready) { HIPCHK(hipEventRecord(c->ev_done[c->row_par], s)); c->row_par = (c->row_par + 1) % LC3D_SETS; }      /* this call's set of rows and records is free again */
     }
     HIPCHK(hipGetLastError());
     c->last_stream = s;
@@ -3316,11 +3333,11 @@ extern "C" int lc3hip_destroy(void* ctx)
     if (c->d_pcm) hipFree(c->d_pcm);
     if (c->d_out) hipFree(c->d_out);
     if (c->d_dump) hipFree(c->d_dump);
-    if (c->d_y12) hipFree(c->d_y12);
+    for (int i = 0; i < LC3D_SETS; i++) if (c->d_y12[i]) hipFree(c->d_y12[i]);
     if (c->d_trace) hipFree(c->d_trace);
     if (c->d_status) hipFree(c->d_status);
-    for (int i = 0; i < 2; i++) { if (c->d_spec[i]) hipFree(c->d_spec[i]); if (c->d_frec[i]) hipFree(c->d_frec[i]); }
-    for (int i = 0; i < 2; i++) if (c->d_xnext[i]) hipFree(c->d_xnext[i]);
+    for (int i = 0; i < LC3D_SETS; i++) { if (c->d_spec[i]) hipFree(c->d_spec[i]); if (c->d_frec[i]) hipFree(c->d_frec[i]); }
+    for (int i = 0; i < LC3D_SETS + 1; i++) if (c->d_xnext[i]) hipFree(c->d_xnext[i]);
     free(c->h_attack);
     for (int i = 0; i < 2; i++) {
         if (c->hp_dpcm[i]) hipFree(c->hp_dpcm[i]);
@@ -3329,7 +3346,8 @@ extern "C" int lc3hip_destroy(void* ctx)
         if (c->ev_k[i]) hipEventDestroy(c->ev_k[i]);
     }
     if (c->s_h2d) hipStreamDestroy(c->s_h2d);
-    if (c->s_pre) { hipStreamDestroy(c->s_pre); hipStreamDestroy(c->s_fr); hipEventDestroy(c->ev_fork); hipEventDestroy(c->ev_done[0]); hipEventDestroy(c->ev_done[1]);
+    if (c->s_pre) { if (c->s_pit != c->s_pre) { hipStreamDestroy(c->s_pit); hipStreamDestroy(c->s_ln); } hipStreamDestroy(c->s_pre); hipStreamDestroy(c->s_fr);
+                    for (int i = 0; i < LC3D_MAX_RUNS; i++) { hipEventDestroy(c->ev_h[i]); hipEventDestroy(c->ev_m[i]); } hipEventDestroy(c->ev_fork); for (int i = 0; i < LC3D_SETS; i++) hipEventDestroy(c->ev_done[i]);
                     for (int i = 0; i < LC3D_MAX_RUNS; i++) { hipEventDestroy(c->ev_p[i]); hipEventDestroy(c->ev_f[i]); } }
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
