@@ -5,7 +5,11 @@ TAG=${1:-pmc}; shift
 ROOT=$PWD; OUT=$ROOT/gpurun_out/$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 i=0
-for C in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_THREAD_CYCLES_VALU" ${PMC_EXTRA:+"$PMC_EXTRA"}; do
+PASSES=("SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_THREAD_CYCLES_VALU")
+if [ -n "$PMC_ONLY" ]; then PASSES=(); fi
+IFS=';' read -ra EXTRA <<< "$PMC_EXTRA"
+for C in "${PASSES[@]}" "${EXTRA[@]}"; do
+  [ -z "$C" ] && continue
   i=$((i+1))
   timeout -k 10 200 rocprofv3 --pmc $C -d $OUT/p$i -o p --output-format csv -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras "$@" > $OUT/p$i.log 2>&1 || { echo "failed pass $i"; tail -5 $OUT/p$i.log; exit 1; }
   echo "progress: pass $i"
