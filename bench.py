@@ -33,12 +33,14 @@ WORKLOADS = {
     "c3": (48000, 10.0, 0, 2, 480, [128000], 16, 2048, "BASELINE configs[2]: stereo streams, 48kHz/10ms/128kbps (80 B per channel); 8 GPUs x 2048 streams x 16 frames = 262144 stereo frames"),
     "c4": (96000, 2.5, 1, 1, 240, [256000], 256, 4096, "BASELINE configs[3]: 96kHz/2.5ms high-resolution 256kbps mono"),
     "c5": (48000, 10.0, 0, 1, 480, RATES12, 64, 4096, "BASELINE configs[4]: mixed-bitrate batch 16-320 kbps, 48kHz/10ms mono"),
+    # the large kernel layout (N = 960): 96 kHz / 10 ms high-resolution
+    "c96": (96000, 10.0, 1, 1, 960, [256000], 32, 4096, "96kHz/10ms high-resolution 256kbps mono (large LDS layout of the kernels)"),
     # decoder: the C1 / C5 bitstreams, produced on the GPU just before, decoded back to 16-bit PCM
     "d1": (48000, 10.0, 0, 1, 480, [64000], 64, 4096, "decoder: the c1 bitstreams back to 16-bit PCM"),
     "d5": (48000, 10.0, 0, 1, 480, RATES12, 64, 4096, "decoder: the c5 bitstreams back to 16-bit PCM"),
 }
 HBM_PEAK_GBS = 8000.0                          # MI355X_MICROARCH.md: 8.0 TB/s spec
-PROFILE_ROUND = "r02"
+PROFILE_ROUND = "r03"
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -71,6 +73,7 @@ def timed_steps(step, steps, warmup, sync, dist=None, device=None):
     if dist is not None: dist.barrier()
     sync()
     wall = time.perf_counter() - t0
+    timed_steps.local_wall = wall                        # this rank's own time (the line reports all of them)
     if dist is not None:
         tw = torch.tensor([wall], dtype=torch.float64, device=device if device is not None else "cpu")
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
@@ -83,9 +86,11 @@ def rank_env():
 
 
 # ----------------------------------------------------------------------------------------------------------------
-def synth_pcm_device(torch, B, T, ch, n, fs, dev, seed):
-    """Deterministic synthetic PCM on the device [B, T, ch, n] int16: 3 sinusoids + coloured noise per channel-stream + a 20 dB
-    transient every 37 frames."""
+def synth_pcm_device(torch, B, T, ch, n, fs, dev, seed, first_stream=0):
+    """Deterministic synthetic PCM on the device [B, T, ch, n] int16, SURVEY 8(d)'s recipe as tests/lc3_harness.py::synth_pcm states it:
+    per channel-stream 3 sinusoids (80 Hz ... 0.4 fs, amplitude 0.02 ... 0.25 FS) + coloured noise at -30 dBFS, a 20 dB step transient every 37
+    frames, the whole at -20 dB; one stream in four strongly periodic (11 harmonics of a 90 ... 380 Hz pitch: the LTPF path); of every 64
+    streams one is digital silence and one full-scale white noise (kinds by global stream index, so every rank sees its share)."""
     g = torch.Generator(device=dev); g.manual_seed(seed)
     S, m = B * ch, T * n
     t = torch.arange(m, device=dev, dtype=torch.float32) / fs
@@ -95,6 +100,11 @@ def synth_pcm_device(torch, B, T, ch, n, fs, dev, seed):
         a = (0.02 + 0.23 * torch.rand(S, 1, device=dev, generator=g)) * 32767.0
         ph = torch.rand(S, 1, device=dev, generator=g) * 6.2831853
         x += a * torch.sin(6.2831853 * f * t[None, :] + ph)
+    kind = (torch.arange(S, device=dev) // ch + first_stream) % 64
+    per = (kind % 4 == 1).to(torch.float32)[:, None]
+    f0 = 90.0 + torch.rand(S, 1, device=dev, generator=g) * 290.0
+    for h in range(1, 12):
+        x += per * (0.12 / h) * 32767.0 * torch.sin(6.2831853 * f0 * h * t[None, :] + h)
     noise = torch.randn(S, m, device=dev, generator=g)
     noise = 0.5 * noise + 0.3 * torch.roll(noise, 1, 1) + 0.15 * torch.roll(noise, 2, 1) + 0.05 * torch.roll(noise, 3, 1)
     x += noise * (32767.0 * 10 ** (-30 / 20))
@@ -103,8 +113,37 @@ def synth_pcm_device(torch, B, T, ch, n, fs, dev, seed):
         a0 = k * n + n // 3
         env[a0:a0 + n // 2] = 10.0
     x = x * env[None, :] * 0.1
+    full = (torch.rand(S, m, device=dev, generator=g) * 65535.0 - 32768.0)
+    x = torch.where((kind == 62)[:, None], full, x)
+    x = torch.where((kind == 63)[:, None], torch.zeros_like(x), x)
     x = x.round().clamp(-32768, 32767).to(torch.int16)
     return x.reshape(B, ch, T, n).permute(0, 2, 1, 3).contiguous()
+
+
+def parity_sample(pcm, out, nbl, br, fs, ms, hr, ch, calls, sample):
+    """The timed launches' own bytes against the CPU oracle (checker only): `sample` streams, every call of the run (warm-up and timed: the
+    encoder's state runs on from call to call over the same PCM), last call's frames compared byte for byte."""
+    import ctypes as C
+    import numpy as np
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "liblc3_oracle_pm.so"))
+    lib.lc3o_encode_batch16_ch.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    T = pcm.shape[1]
+    frames = differ = 0
+    for i in sample:
+        x = pcm[i:i + 1].cpu().numpy()                                      # [1, T, ch, n]
+        x = np.ascontiguousarray(np.concatenate([x] * calls, axis=1))
+        stride = int(out.shape[2])
+        want = np.zeros((1, T * calls, stride), np.uint8)
+        rate = np.array([br[i]], np.int32)
+        rc = lib.lc3o_encode_batch16_ch(fs, ms, hr, ch, 1, T * calls, rate.ctypes.data, x.ctypes.data, want.ctypes.data, stride)
+        if rc: raise RuntimeError("oracle rc %d" % rc)
+        got = out[i].cpu().numpy()
+        nb = nbl[i]
+        d = (got[:, :nb] != want[0, -T:, :nb]).any(axis=1)
+        frames += T * ch; differ += int(d.sum()) * ch
+    return {"frames": frames, "differ": differ, "streams": len(sample),
+            "note": "oracle/liblc3_oracle_pm.so over all %d calls of the run on the sampled streams (state runs on), the last call's frames compared with "
+                    "the timed launches' output buffer byte for byte" % calls}
 
 
 def cpu_baseline(kind_dir, mode, fs, ms, hr, ch, rate_or_nbytes, sample, S, T, tag):
@@ -135,6 +174,17 @@ def cpu_baseline(kind_dir, mode, fs, ms, hr, ch, rate_or_nbytes, sample, S, T, t
                       % (tag, S, T, "PCM" if mode == "enc" else "bitstreams", cores, sec, sec * cores, max(1, S // 16), sec1)}
 
 
+def source_hash():
+    """sha256 over the kernel / host sources of the library: committed counters (profiles/*_counters.json) carry it, and the bench line only
+    quotes them when it matches the tree that is running."""
+    import glob, hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "audio_codec_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.inc")) + glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "*.c"))):
+        with open(f, "rb") as fh: h.update(os.path.basename(f).encode()); h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def committed_profile(workload, B, T):
     """Numbers that come from separate rocprofv3 passes (committed under profiles/, collected with tools/gpu_round.sh on the same
     command): HBM traffic per launch (FETCH_SIZE x 2 + WRITE_SIZE) and wave-level VALU instructions per launch.  Only valid for the
@@ -145,10 +195,29 @@ def committed_profile(workload, B, T):
                 t = json.load(f)
             for e in [t] + list(t.get("more", [])):
                 if e.get("workload") == workload and e.get("streams") == B and e.get("frames") == T:
+                    e = dict(e); e["source_head"] = t.get("source_head"); e["stale"] = t.get("source_head") != source_hash()
                     return e
         except (OSError, KeyError, ValueError):
             pass
     return {}
+
+
+def quick_workload(torch, amd, name, dev, local, steps=3, warmup=1):
+    """Another BASELINE configuration on this GPU, a few steps (the default line's `other_workloads`; the full lines: --workload NAME)."""
+    fs, ms, hr, ch, n, rates, T, B, what = WORKLOADS[name]
+    pcm = synth_pcm_device(torch, B, T, ch, n, fs, dev, seed=4321)
+    br = [rates[i % len(rates)] for i in range(B)]
+    batch = amd.Batch(B, fs, ch, ms, hr, br, device=local)
+    out = torch.zeros(B, T, batch.stride, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    batch.set_input_ready(True)
+    step = lambda: batch.encode_device(pcm.data_ptr(), 16, T, out.data_ptr(), batch.stride, hip_stream=stream.cuda_stream, sync=False)
+    w = timed_steps(step, steps, warmup, lambda: torch.cuda.synchronize(dev))
+    ok = bool(out[:, -1].ne(0).any().item())
+    batch.close(); del pcm, out
+    torch.cuda.empty_cache()
+    return {"value": round(B * T * ch * steps / w / 1e6, 3), "unit": "M channel-frames/s", "ms_per_step": round(w / steps * 1e3, 3), "steps": steps,
+            "config": "%d streams x %d frames, %d ch, %d Hz / %g ms%s" % (B, T, ch, fs, ms, " hr" if hr else ""), "nonempty": ok}
 
 
 def main():
@@ -159,6 +228,7 @@ def main():
     ap.add_argument("--streams", type=int, default=0, help="independent streams per GPU (default: the workload's; c1: 4096 = BASELINE configs[1])")
     ap.add_argument("--frames", type=int, default=0, help="frames per stream per step (default: the workload's; c1: 64, SURVEY 8(d))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the check of the timed launches' bytes against the CPU oracle")
     ap.add_argument("--no-extras", action="store_true", help="skip the host-I/O and T = 1 side measurements of the default line")
     ap.add_argument("--serial-calls", action="store_true", help="encoder: do not declare the PCM ready ahead of the calls (no overlap between consecutive calls)")
     ap.add_argument("--workload", default="c1", choices=sorted(WORKLOADS), help="c1 = BASELINE configs[1] (the metric's configuration)")
@@ -196,7 +266,7 @@ def main():
     from audio_codec_amd.sharding import stream_block
     first, last = stream_block(rank, world, B * world)          # weak scaling: every rank owns B of the B*world streams
     assert last - first == B
-    pcm = synth_pcm_device(torch, B, T, ch, n, fs, dev, seed=1234 + first)
+    pcm = synth_pcm_device(torch, B, T, ch, n, fs, dev, seed=1234 + first, first_stream=first)
     br = [rates[(first + i) % len(rates)] for i in range(B)]
     batch = audio_codec_amd.Batch(B, fs, ch, ms, hr, br, device=local)
     stride = batch.stride
@@ -224,10 +294,24 @@ def main():
         if count[0] == a.warmup + a.steps: e1.record(stream)
 
     wall = timed_steps(timed_step, a.steps, a.warmup, lambda: torch.cuda.synchronize(dev), dist, dev)
+    wall_local = timed_steps.local_wall
     kern_ms = e0.elapsed_time(e1) / a.steps
+    par = None
     if not decode:
         nz = int(out[:, -1, :min(nbl)].ne(0).any(dim=1).sum().item())
         assert nz > 0.9 * B, "encoder produced empty frames"
+        if rank == 0 and not a.no_parity:
+            # the bytes of the timed launches themselves against the CPU oracle, before anything else touches the batch
+            try:
+                smp = sorted({i for i in (0, 1, 2, 5, 21, 62, 63, B // 2, B - 1) if 0 <= i < B})
+                par = parity_sample(pcm, out, nbl, br, fs, ms, hr, ch, a.warmup + a.steps, smp)
+            except Exception as ex:
+                par = {"frames": 0, "differ": None, "note": "failed: %r" % (ex,)}
+    per_rank_ms = [round(wall_local / a.steps * 1e3, 4)]
+    if dist is not None:
+        tw = torch.zeros(world, dtype=torch.float64, device=dev); tw[rank] = wall_local
+        dist.all_reduce(tw)
+        per_rank_ms = [round(float(v) / a.steps * 1e3, 4) for v in tw.tolist()]
 
     if rank == 0:
         units = B * T * ch                                   # channel-frames per step per GPU
@@ -236,8 +320,9 @@ def main():
         achieved = algo / (kern_ms * 1e-3) / 1e9
         prof = committed_profile(a.workload, B, T)
         kernels = ("lc3_dec_parse_kernel + lc3_dec_plc_kernel + lc3_dec_imdct_kernel + lc3_dec_synth_kernel" if decode else
-                   "lc3_enc_resample/hp50/pitch_kernel (pitch chain) || lc3_enc_front/attack/snsvq_kernel (frame-parallel front) -> lc3_enc_seq_kernel (rate chain), "
-                   "runs of 8 frames on three HIP streams, then lc3_enc_pack_kernel")
+                   "lc3_enc_resample/hp50/pitch_kernel (pitch chain) || lc3_enc_front_kernel (MDCT, wave per frame) -> lc3_enc_scf_lane/attack/snsvq/shape_lane_kernel "
+                   "(one frame per lane) -> lc3_enc_rate_kernel (rate chain, wave per stream) -> lc3_enc_pack_kernel (tail + bitstream writer, one frame per lane); "
+                   "three HIP streams, up to three calls in flight")
         res = {
             "metric": "Mframes/s encoded (48kHz/10ms/64kbps)" if a.workload == "c1" else "Mframes/s %s (channel-frames)" % ("decoded" if decode else "encoded"),
             "value": round(value, 4), "unit": "Mframes/s",
@@ -247,14 +332,22 @@ def main():
                        "streams_per_gpu": B, "frames_per_step": T, "channels": ch, "bytes_per_frame": sorted(set(nbl)),
                        "stereo_frames_per_step_all_gpus": B * T * world if ch == 2 else None,
                        "parallelism": "streams sharded over %d GPU(s) by contiguous blocks, no collectives" % world,
-                       "input_ready": (not decode and not a.serial_calls)},
+                       "input_ready": (not decode and not a.serial_calls),
+                       "pcm": "synthetic, SURVEY 8(d) recipe as tests/lc3_harness.py states it (3 sinusoids + coloured noise + 20 dB transients at -20 dB; "
+                              "1/4 of the streams strongly periodic, 1/64 digital silence, 1/64 full-scale white noise)"},
+            "per_rank_ms": per_rank_ms,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": prof.get("traffic_bytes"),
+                         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None if prof.get("stale") else prof.get("traffic_bytes"),
                          "kernel": kernels + " (one call = these launches; HIP events on the launch stream around all of them)",
                          "kernel_ms_avg": round(kern_ms, 4), "algorithmic_bytes_per_launch": algo,
                          "note": "not HBM bound (SURVEY 8d): see roofline_valu and DESIGN.md section 5"},
         }
+        if par is not None: res["parity_sample"] = par
+        if prof.get("stale"):
+            res["roofline"]["traffic_note"] = "profiles/%s_counters.json was collected on other sources (%s, running %s): not quoted" % (PROFILE_ROUND, prof.get("source_head"), source_hash())
+            prof = {}
         if prof.get("traffic_bytes"):
+            res["roofline"]["traffic_over_algorithmic"] = round(prof["traffic_bytes"] / algo, 2)
             # what the hand-overs between the kernels cost: measured HBM traffic of one call over the call's duration, against the same peak
             tr = prof["traffic_bytes"] / (kern_ms * 1e-3) / 1e9
             res["roofline"]["traffic_gbps"] = round(tr, 1)
@@ -273,18 +366,17 @@ def main():
                                     "frac": round(ach / peak, 4), "valu_insts_per_launch": prof["valu_insts"], "clock_ghz": clk,
                                     "lane_utilisation": prof.get("valu_lane_util"),
                                     "source": "profiles/%s_counters.json (SQ_INSTS_VALU, separate rocprofv3 --pmc pass of this command)" % PROFILE_ROUND}
-            # what this instruction mix is actually up against: wave-instructions of the counted kinds (vector, scalar, LDS, vector memory)
-            # issued per SIMD cycle, next to the rate at which a SIMD issues co-resident DEPENDENT chains (tools/ubench/issue.hip,
-            # profiles/r02_issue_rate.txt: one v_fma per 4.0 cycles with four such waves, 2.95 with eight).  One wave per stream and
-            # 4096 streams on 1024 SIMDs are four serial chains per SIMD; the kernels beside them add a fifth and sixth.
+            res["roofline_valu"]["source_head"] = prof.get("source_head")
+            lu = prof.get("valu_lane_util")
+            if lu: res["roofline_valu"]["frac_of_lane_peak"] = round(ach / peak * lu, 4)      # 2-cycle VALU peak x the share of lanes the EXEC mask enables
             pk = prof.get("per_kernel") or {}
             counted = sum(v.get(c, 0) for v in pk.values() for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD"))
             if counted:
                 per_cycle = counted / 1024.0 / (kern_ms * 1e-3 * clk * 1e9)
                 res["roofline_valu"]["issue"] = {"insts_per_simd_cycle": round(per_cycle, 3), "counted_insts_per_launch": int(counted),
-                                                 "dependent_chains_4_waves": round(1 / 4.0, 3), "dependent_chains_8_waves": round(1 / 2.95, 3),
-                                                 "frac_of_8_wave_rate": round(per_cycle * 2.95, 3),
-                                                 "note": "branches, waits and scalar memory instructions are not in the counted kinds (+ ~12 %)"}
+                                                 "insts_per_frame": round(counted / units, 1),
+                                                 "note": "vector, scalar, LDS and vector-memory-read instructions of all kernels of a call per SIMD cycle; branches, waits and "
+                                                         "scalar loads are not counted (+ ~10 %)"}
         if not decode and not a.no_extras and not a.serial_calls:
             # the same steps without the input-ready promise: every call waits for the previous one to drain
             batch.set_input_ready(False)
@@ -316,6 +408,14 @@ def main():
             w1 = timed_steps(t1, 200, 20, lambda: torch.cuda.synchronize(dev))
             res["t1"] = {"value": round(B * 200 / w1 / 1e6, 4), "unit": "Mframes/s", "ms_per_step": round(w1 / 200 * 1e3, 4),
                          "note": "%d streams x 1 frame per call (launch-latency regime: the kernels of a call run back to back on one stream)" % B}
+        if a.workload == "c1" and not a.no_extras and world == 1:
+            # the other BASELINE configurations, three steps each (their own lines with rooflines: --workload c3 / c4 / c5 / c96)
+            res["other_workloads"] = {}
+            for wn in ("c3", "c4", "c5", "c96"):
+                try:
+                    res["other_workloads"][wn] = quick_workload(torch, audio_codec_amd, wn, dev, local)
+                except Exception as ex:
+                    res["other_workloads"][wn] = {"value": None, "note": "failed: %r" % (ex,)}
         if not a.no_cpu_baseline:
             try:
                 S = min(B, 2048 if not decode else 2048)

@@ -1,0 +1,25 @@
+"""GPU frames against the compiled ETSI REFERENCE (not the restatement) over the five BASELINE configurations, reduced size (the full-size
+run: tools/ref_soak.py, recorded in profiles/): frames are compared byte for byte; where run-time libm calls flip a decision between the
+device and glibc the stream's two bitstreams are decoded by the reference decoder and the ETSI mld tool must stay
+within the conformance procedure's threshold of 4 (E/conformance/lc3_conformance.py:126-129)."""
+import os
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def test_reference_soak_reduced():
+    import ref_soak
+    if not (ref_soak.have_ref() and os.path.exists(ref_soak.REF_BENCH)):
+        pytest.skip("oracle/_ref did not travel")
+    res = ref_soak.run(scale=0.03, verbose=False)
+    tot = sum(r["channel_frames"] for r in res); diff = sum(r["frames_differ"] for r in res)
+    assert tot > 10000
+    # identical frames are the rule; a libm-boundary flip is allowed only inside the conformance tolerance
+    assert diff <= tot // 500, (diff, tot, res)
+    for r in res:
+        assert r["worst_mld"] is None or r["worst_mld"] <= 4.0, r
