@@ -1814,8 +1814,10 @@ __device__ __forceinline__ int gain_probe_len(float thr7, const float* ev /* [NQ
     return uni(len);
 }
 
-__device__ __forceinline__ bool gain_probe(float thr7, float thr50, const float* en, int nq, int cand, float target)
+/* en[j] = enb[LC3D_ROW_OFF(e0 + j, RT)]: the energies of a tiled spectrum row (lc3_plan.h), or a plain array with e0 = 0, RT = 1 */
+__device__ __forceinline__ bool gain_probe(float thr7, float thr50, const float* enb, int e0, int RT, int nq, int cand, float target)
 {
+#define en_(j_) enb[LC3D_ROW_OFF(e0 + (j_), RT)]
     float ener = 0; bool iszero = true;
     const float fc = (float)cand;
     /* one step of R/estimate_global_gain.c:103-121, branch-free.  All four outcomes have the form (float)(((double)ener + X) + Y):
@@ -1831,9 +1833,10 @@ __device__ __forceinline__ bool gain_probe(float thr7, float thr50, const float*
         const int y_h0 = opaque_i(hi ? chi_h : 0), y_h = opaque_i(lonz ? clo_h : y_h0), y_l = opaque_i(lonz ? clo_l : 0); \
         ener = (float)(((double)ener + (double)xf) + __hiloint2double(y_h, y_l)); iszero = iszero && lo; } while (0)
     int j = nq - 1;
-    for (; j >= 3; j -= 4) { const float v0 = en[j], v1 = en[j - 1], v2 = en[j - 2], v3 = en[j - 3]; GSTEP(v0); GSTEP(v1); GSTEP(v2); GSTEP(v3); }
-    for (; j >= 0; j--) GSTEP(en[j]);
+    for (; j >= 3; j -= 4) { const float v0 = en_(j), v1 = en_(j - 1), v2 = en_(j - 2), v3 = en_(j - 3); GSTEP(v0); GSTEP(v1); GSTEP(v2); GSTEP(v3); }
+    for (; j >= 0; j--) GSTEP(en_(j));
 #undef GSTEP
+#undef en_
     return ener > target && !iszero;
 }
 
@@ -1925,7 +1928,7 @@ template <class LdsT> STAGE void st_gain_estimate(const lc3d_plan* __restrict__ 
                 const float margin = 4e-5f * S + 1e-4f;
                 if (S - margin > target) addback = true;
                 else if (S + margin < target) addback = false;
-                else addback = gain_probe(thr7, thr50, en, nq, cand, target);         /* too close to call: the reference's serial sum */
+                else addback = gain_probe(thr7, thr50, en, 0, 1, nq, cand, target);         /* too close to call: the reference's serial sum */
             }
             if (!addback) m += fac;
         }
@@ -1947,8 +1950,8 @@ template <class LdsT> STAGE void st_gain_estimate(const lc3d_plan* __restrict__ 
 /* ---- the stateless half of the global-gain estimate (R/estimate_global_gain.c:52-91): spectrum maximum -> smallest gain index,
  * the high-resolution regulariser, the per-4-bin log energies en[].  Runs in lc3_enc_shape_kernel for all frames at once; the
  * half that reads what the previous frame left (the rate loop and the bisection against its target, :42-50, :93-137) is
- * lc3_enc_rate_kernel.  en[] goes to `en_out` (global, nq floats), ind_min and the all-zero flag to the record. ---- */
-template <class LdsT> STAGE void st_gain_prep(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ C, LdsT& L, int lane, float* __restrict__ en_out, float* __restrict__ rec)
+ * lc3_enc_rate_kernel.  en[] goes behind the ylen lines of the frame's row, ind_min and the all-zero flag to the record. ---- */
+template <class LdsT> STAGE void st_gain_prep(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ C, LdsT& L, int lane, float* __restrict__ row /* tiled (lc3_plan.h) */, int e0, int RT, float* __restrict__ rec)
 {
     const int lg = PI(ylen), off = CI(gg_off), nq = lg >> 2;
     float xm = 0;
@@ -1979,7 +1982,7 @@ template <class LdsT> STAGE void st_gain_prep(const lc3d_plan* __restrict__ P, c
                 const float* x = &L.A[4 * j];
                 float t = x[0] * x[0];
                 t += x[1] * x[1]; t += x[2] * x[2]; t += x[3] * x[3];
-                en_out[j] = (float)((28.0 / 20.0) * (7 + 10.0 * (double)m_log10f(t + reg_val + PF(c_2m31))));
+                row[LC3D_ROW_OFF(e0 + j, RT)] = (float)((28.0 / 20.0) * (7 + 10.0 * (double)m_log10f(t + reg_val + PF(c_2m31))));
             }
         }
     }

@@ -94,6 +94,11 @@ typedef struct {
 /* spectrum row of the pipelined encoder path, per channel-frame: [0, ylen) the MDCT spectrum (lc3_enc_front_kernel), shaped and TNS-filtered in
  * place by lc3_enc_shape_kernel, which appends the ylen / 4 log energies of the gain estimate; rows are SROW words apart */
 #define LC3D_SROW(ylen) (((ylen) + ((ylen) >> 2) + 15) & ~15)
+/* Storage: a row is SROW / 16 chunks of 16 floats, and chunk c of row (cs, t) lies at ((cs * NCH + c) * RT + t) * 16 (RT rows per channel-stream):
+ * the same chunk of consecutive frames of a stream is adjacent in memory.  The one-frame-per-lane kernels give 64 consecutive frames to the
+ * 64 lanes of a wave, so each of their 64-byte-per-lane accesses is one 4 KB run; a wave that owns one frame reads 64-byte segments. */
+#define LC3D_ROW_BASE(rows, cs, t, RT, srow) ((rows) + (((size_t)(cs) * ((srow) >> 4)) * (size_t)(RT) + (size_t)(t)) * 16)
+#define LC3D_ROW_OFF(k, RT) (((((size_t)((k) >> 4)) * (size_t)(RT)) << 4) + (size_t)((k) & 15))
 
 /* per channel-frame status bits of the encoder: conditions the reference only asserts on (SURVEY 5 "failure detection") */
 #define LC3D_ENC_ST_BIT_BUDGET  1        /* side information + range-coder bits exceed the frame (R/ari_codec.c:777) */

@@ -2,8 +2,8 @@
 # One batched GPU-box session for the record: bench lines of every workload, rocprofv3 kernel stats and separate PMC passes of the
 # default bench command (counters and traces never in one run), distilled into profiles/<tag>_*.  Usage: bash tools/gpu_round.sh <tag> [workloads]
 set -e
-TAG=${1:-r02}
-WL=${2:-"c1 c3 c4 c5 d1 d5"}
+TAG=${1:-r03}
+WL=${2:-"c1 c3 c4 c5 c96 d1 d5"}
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT $ROOT/profiles
@@ -64,7 +64,11 @@ for w, B, T in (("c1", 4096, 64), ("d1", 4096, 64)):
          "per_kernel": {k: {c: v for (kk, c), v in summ[w].items() if kk == k} for k in sorted({kk for kk, _ in summ[w]})}}
     ents.append(e)
 if ents:
+    import sys
+    sys.path.insert(0, "$ROOT")
+    import bench
     top = ents[0]; top["more"] = ents[1:]
+    top["source_head"] = bench.source_hash()       # the sources these counters were collected on: bench.py quotes them only while it matches
     top["source"] = "tools/gpu_round.sh %s: separate rocprofv3 --pmc passes of python3 bench.py --workload W --steps 2 --warmup 1; all lc3_* kernels of one call summed, mean over launches; FETCH_SIZE doubled per MI355X_MICROARCH.md; lane utilisation = SQ_THREAD_CYCLES_VALU / (SQ_INSTS_VALU x 64): the share of lanes the EXEC mask enables per vector instruction (calibration: 64.0 for lc3_enc_hp50_kernel, whose lanes are all live)" % tag
     json.dump(top, open("profiles/%s_counters.json" % tag, "w"), indent=1)
 print(open("profiles/%s_c1_pmc.txt" % tag).read()[:3000])
