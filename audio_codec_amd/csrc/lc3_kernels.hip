@@ -3123,11 +3123,11 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
             if (scf_wave < 0) { const char* e = getenv("LC3PLUS_ENC_SCF_WAVE"); scf_wave = e && e[0] == '1'; }     /* diagnostic: energies / scale factors in the front kernel */
             const int fpw = nt < FRONT_FPW ? nt : FRONT_FPW;
             const unsigned fruns = (unsigned)((nt + fpw - 1) / fpw);
-            if (c->big) hipLaunchKernelGGL(lc3_enc_front_kernel_big, dim3((unsigned)c->ncs * fruns), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames, tb, nt, fpw, c->ncs, dspec, c->srow, dT, dt0, dfrec, xn_w, xprev, xprev_stride, 1);
+            if (c->big) hipLaunchKernelGGL(lc3_enc_front_kernel_big, dim3((unsigned)c->ncs * fruns), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames, tb, nt, fpw, c->ncs, dspec, c->srow, dT, dt0, dfrec, xn_w, xprev, xprev_stride, scf_wave);
             else DUPL('f') hipLaunchKernelGGL(lc3_enc_front_kernel, dim3((unsigned)c->ncs * fruns), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames, tb, nt, fpw, c->ncs, dspec, c->srow, dT, dt0, dfrec, xn_w, xprev, xprev_stride, scf_wave);
             HIPCHK(hipEventRecord(c->ev_m[k], c->s_fr));                 /* the MDCT memory hand-over and the spectrum rows of the run are written */
             if (five) HIPCHK(hipStreamWaitEvent(c->s_ln, c->ev_m[k], 0));
-            if (!c->big && !scf_wave) DUPL('e') hipLaunchKernelGGL(lc3_enc_scf_lane_kernel, dim3((unsigned)(((long long)c->ncs * nt + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->s_ln, c->d_plan, dT, dt0 + tb, nt, c->ncs, dspec, c->srow, dfrec);
+            if (!scf_wave) DUPL('e') hipLaunchKernelGGL(lc3_enc_scf_lane_kernel, dim3((unsigned)(((long long)c->ncs * nt + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->s_ln, c->d_plan, dT, dt0 + tb, nt, c->ncs, dspec, c->srow, dfrec);
             if (c->any_attack)
                 hipLaunchKernelGGL(lc3_enc_attack_kernel, dim3((unsigned)((c->ncs + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->s_ln, c->d_plan, c->d_chans, c->d_state, c->state_words, LC3D_ST_SCAL(mc), dfrec, dT, dt0, tb, nt, c->ncs);
             const long long nfr = (long long)c->ncs * nt;
@@ -3143,8 +3143,8 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
                 if (son) { HIPCHK(hipEventRecord(c->ev_f[k], c->s_ln)); HIPCHK(hipStreamWaitEvent(s, c->ev_f[k], 0)); }
                 static int swave = -1;
                 if (swave < 0) { const char* e = getenv("LC3PLUS_ENC_SHAPE_WAVE"); swave = e && e[0] == '1'; }     /* diagnostic: the wave-per-frame kernel */
-                if (c->big) hipLaunchKernelGGL(lc3_enc_shape_kernel_big, dim3((unsigned)c->ncs * sruns), dim3(WAVE), 0, ss, c->d_plan, c->d_chans, dT, dt0 + tb, nt, spw, c->ncs, dspec, c->srow, dfrec);
-                else if (!swave) DUPL('a') hipLaunchKernelGGL(lc3_enc_shape_lane_kernel, dim3((unsigned)(((long long)c->ncs * nt + WAVE - 1) / WAVE)), dim3(WAVE), 0, ss, c->d_plan, c->d_chans, dT, dt0 + tb, nt, c->ncs, dspec, c->srow, dfrec);
+                if (!swave) DUPL('a') hipLaunchKernelGGL(lc3_enc_shape_lane_kernel, dim3((unsigned)(((long long)c->ncs * nt + WAVE - 1) / WAVE)), dim3(WAVE), 0, ss, c->d_plan, c->d_chans, dT, dt0 + tb, nt, c->ncs, dspec, c->srow, dfrec);
+                else if (c->big) hipLaunchKernelGGL(lc3_enc_shape_kernel_big, dim3((unsigned)c->ncs * sruns), dim3(WAVE), 0, ss, c->d_plan, c->d_chans, dT, dt0 + tb, nt, spw, c->ncs, dspec, c->srow, dfrec);
                 else DUPL('a') hipLaunchKernelGGL(lc3_enc_shape_kernel, dim3((unsigned)c->ncs * sruns), dim3(WAVE), 0, ss, c->d_plan, c->d_chans, dT, dt0 + tb, nt, spw, c->ncs, dspec, c->srow, dfrec);
                 HIPCHK(hipGetLastError());
                 if (!son) { HIPCHK(hipEventRecord(c->ev_f[k], c->s_ln)); HIPCHK(hipStreamWaitEvent(s, c->ev_f[k], 0)); }
