@@ -3120,7 +3120,7 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
                 DUPL('r') hipLaunchKernelGGL(lc3_enc_resample_kernel, dim3((unsigned)c->ncs * pruns), dim3(WAVE), 0, c->s_pre, c->d_plan, c->d_state, c->state_words, mc, dpcm, bitdepth, n_frames, hb, hn, c->ncs, dy12, xprev, xprev_stride);
                 DUPL('h') hipLaunchKernelGGL(lc3_enc_hp50_kernel, dim3((unsigned)((c->ncs + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->s_pre, c->d_plan, c->d_state, c->state_words, LC3D_ST_SCAL(mc), n_frames, hb, hn, c->ncs, dy12);
                 {   /* the stateless part of the open-loop pitch analysis for these frames: decimation (one sample per lane), then one frame per lane */
-                    const int l2 = c->len12 >> 1, mcnt = hn * l2, per = (mcnt + (hb == 0 ? D6_PRE : 0) + WAVE - 1) / WAVE;
+                    const int l2 = c->len12 >> 1, mcnt = hn * l2, per = (mcnt + WAVE * DEC6_PER - 1) / (WAVE * DEC6_PER) + (hb == 0 ? 1 : 0);     /* first piece: one wave more, for the state's samples */
                     DUPL('d') hipLaunchKernelGGL(lc3_enc_dec6_kernel, dim3((unsigned)c->ncs * per), dim3(WAVE), 0, c->s_pre, c->d_plan, c->d_state, c->state_words, mc, dy12, n_frames, hb * l2, mcnt, per, c->ncs, dd6, d6s);
                     DUPL('o') hipLaunchKernelGGL(lc3_enc_olpa_lane_kernel, dim3((unsigned)(((long long)c->ncs * hn + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->s_pre, c->d_plan, n_frames, hb, hn, c->ncs, dd6, d6s, dol);
                 }
