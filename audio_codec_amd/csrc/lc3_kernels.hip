@@ -2868,7 +2868,6 @@ KERNEL_NAME(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans
 /* C-ABI device shim (lc3_shim.h): context, uploads, launch                                          */
 /* ------------------------------------------------------------------------------------------------ */
 #include "lc3_enc_front.inc"       /* lc3_enc_front_kernel (or _big): the stateless front, frame-parallel */
-#include "lc3_enc_olpa.inc"        /* lc3_enc_dec6_kernel, lc3_enc_olpa_lane_kernel: the stateless part of the open-loop pitch analysis */
 #include "lc3_enc_seq.inc"         /* lc3_enc_pitch_kernel: the pitch chain of the pipelined path */
 #include "lc3_enc_rate.inc"        /* lc3_enc_shape_kernel, lc3_enc_rate_kernel, lc3_enc_tail_kernel (or _big): the rate chain and its frame-parallel neighbours */
 #include "lc3_dec_kernels.inc"     /* lc3_dec_{plc,imdct,synth}_kernel, or the _big imdct / synth kernels in the large-layout object */
@@ -2899,7 +2898,7 @@ struct lc3hip_ctx {
     lc3d_plan* d_plan; lc3d_chan* d_chans; float* d_state;
     void* d_pcm; size_t pcm_cap; uint8_t* d_out; size_t out_cap;
     lc3d_trace* d_trace; size_t trace_cap;
-    int* d_dump; size_t dump_cap; int hr, fused; float* d_y12[LC3D_SETS]; size_t y12_cap[LC3D_SETS]; float* d_d6[LC3D_SETS]; size_t d6_cap[LC3D_SETS]; float* d_ol[LC3D_SETS]; size_t ol_cap[LC3D_SETS]; int len12;
+    int* d_dump; size_t dump_cap; int hr, fused; float* d_y12[LC3D_SETS]; size_t y12_cap[LC3D_SETS];
     uint8_t* d_status; size_t status_cap; int status_frames;
     float* d_spec[LC3D_SETS]; size_t spec_cap[LC3D_SETS]; float* d_frec[LC3D_SETS]; size_t frec_cap[LC3D_SETS]; hipEvent_t ev_done[LC3D_SETS]; float* d_xnext[LC3D_SETS + 1]; int xn_par, row_par; uint8_t* h_attack; int any_attack;
     int input_ready, ahead_ok, ahead_T, ahead_R;   /* lc3hip_set_input_ready: side kernels of a call beside the previous call's tail */   /* split path (lc3_enc_front.inc) */      /* per channel-frame status bits of the last call (LC3D_ENC_ST_*) */
@@ -2930,7 +2929,7 @@ extern "C" int lc3hip_create(void** out_ctx, const lc3d_plan* plan, int n_stream
     HIPCHK_OR(hipSetDevice(device), free(c));
     c->n_streams = n_streams; c->channels = plan->channels; c->ncs = n_streams * plan->channels; c->N = plan->N;
     c->big = LC3D_LAYOUT_BIG(plan->N, plan->la);
-    c->hr = plan->hrmode; c->ylen = plan->ylen; c->srow = LC3D_SROW(plan->ylen); c->len12 = plan->len12;
+    c->hr = plan->hrmode; c->ylen = plan->ylen; c->srow = LC3D_SROW(plan->ylen);
     { const char* e = getenv("LC3PLUS_ENC_FUSED"); c->fused = e && e[0] == '1'; }     /* diagnostic: the bitstream writer inside lc3_encode_kernel */
     c->state_words = LC3D_STATE_WORDS(c->big ? LC3D_MEMCAP_BIG : LC3D_MEMCAP_STD);
     HIPCHK_OR(hipMalloc((void**)&c->d_plan, sizeof(lc3d_plan)), lc3hip_destroy(c));
@@ -3053,12 +3052,6 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
         const size_t ns = (size_t)c->ncs * dT * c->srow, nr = (size_t)c->ncs * dT * FR_WORDS;
         if (c->spec_cap[hb_] < ns) { if (c->d_spec[hb_]) HIPCHK(hipFree(c->d_spec[hb_])); c->d_spec[hb_] = nullptr; c->spec_cap[hb_] = 0; HIPCHK(hipMalloc((void**)&c->d_spec[hb_], ns * sizeof(float))); c->spec_cap[hb_] = ns; }
         if (c->frec_cap[hb_] < nr) { if (c->d_frec[hb_]) HIPCHK(hipFree(c->d_frec[hb_])); c->d_frec[hb_] = nullptr; c->frec_cap[hb_] = 0; HIPCHK(hipMalloc((void**)&c->d_frec[hb_], nr * sizeof(float))); c->frec_cap[hb_] = nr; }
-        /* the 6.4 kHz stream of the launch (behind the state's 194 samples) and the open-loop pitch rows (lc3_enc_olpa.inc) */
-        const int d6s = (D6_PRE + n_frames * (c->len12 >> 1) + 3) & ~3;
-        { const size_t n6 = (size_t)c->ncs * d6s, no = (size_t)c->ncs * n_frames * OLW;
-          if (c->d6_cap[hb_] < n6) { if (c->d_d6[hb_]) HIPCHK(hipFree(c->d_d6[hb_])); c->d_d6[hb_] = nullptr; c->d6_cap[hb_] = 0; HIPCHK(hipMalloc((void**)&c->d_d6[hb_], n6 * sizeof(float))); c->d6_cap[hb_] = n6; }
-          if (c->ol_cap[hb_] < no) { if (c->d_ol[hb_]) HIPCHK(hipFree(c->d_ol[hb_])); c->d_ol[hb_] = nullptr; c->ol_cap[hb_] = 0; HIPCHK(hipMalloc((void**)&c->d_ol[hb_], no * sizeof(float))); c->ol_cap[hb_] = no; } }
-        float* dd6 = c->d_d6[hb_]; float* dol = c->d_ol[hb_];
         for (int i = 0; i < LC3D_SETS + 1; i++) if (!c->d_xnext[i]) HIPCHK(hipMalloc((void**)&c->d_xnext[i], (size_t)c->ncs * mc * sizeof(float)));
         if (!c->s_pre) {
             HIPCHK(hipStreamCreateWithFlags(&c->s_pre, hipStreamNonBlocking)); HIPCHK(hipStreamCreateWithFlags(&c->s_fr, hipStreamNonBlocking));
@@ -3119,16 +3112,11 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
                 const unsigned pruns = (unsigned)((hn + PRE_FPW - 1) / PRE_FPW);
                 DUPL('r') hipLaunchKernelGGL(lc3_enc_resample_kernel, dim3((unsigned)c->ncs * pruns), dim3(WAVE), 0, c->s_pre, c->d_plan, c->d_state, c->state_words, mc, dpcm, bitdepth, n_frames, hb, hn, c->ncs, dy12, xprev, xprev_stride);
                 DUPL('h') hipLaunchKernelGGL(lc3_enc_hp50_kernel, dim3((unsigned)((c->ncs + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->s_pre, c->d_plan, c->d_state, c->state_words, LC3D_ST_SCAL(mc), n_frames, hb, hn, c->ncs, dy12);
-                {   /* the stateless part of the open-loop pitch analysis for these frames: decimation (one sample per lane), then one frame per lane */
-                    const int l2 = c->len12 >> 1, mcnt = hn * l2, per = (mcnt + WAVE * DEC6_PER - 1) / (WAVE * DEC6_PER) + (hb == 0 ? 1 : 0);     /* first piece: one wave more, for the state's samples */
-                    DUPL('d') hipLaunchKernelGGL(lc3_enc_dec6_kernel, dim3((unsigned)c->ncs * per), dim3(WAVE), 0, c->s_pre, c->d_plan, c->d_state, c->state_words, mc, dy12, n_frames, hb * l2, mcnt, per, c->ncs, dd6, d6s);
-                    DUPL('o') hipLaunchKernelGGL(lc3_enc_olpa_lane_kernel, dim3((unsigned)(((long long)c->ncs * hn + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->s_pre, c->d_plan, n_frames, hb, hn, c->ncs, dd6, d6s, dol);
-                }
                 HIPCHK(hipGetLastError());
                 hb += hn; hk++;
                 if (five) { HIPCHK(hipEventRecord(c->ev_h[k], c->s_pre)); HIPCHK(hipStreamWaitEvent(c->s_pit, c->ev_h[k], 0)); }
             }
-            DUPL('p') hipLaunchKernelGGL(lc3_enc_pitch_kernel, dim3(c->ncs), dim3(WAVE), 0, c->s_pit, c->d_plan, c->d_chans, c->d_state, c->state_words, mc, dy12, n_frames, tb, nt, c->ncs, dfrec, dT, dt0, dd6, d6s, dol);
+            DUPL('p') hipLaunchKernelGGL(lc3_enc_pitch_kernel, dim3(c->ncs), dim3(WAVE), 0, c->s_pit, c->d_plan, c->d_chans, c->d_state, c->state_words, mc, dy12, n_frames, tb, nt, c->ncs, dfrec, dT, dt0);
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(c->ev_p[k], c->s_pit));
             static int scf_wave = -1;
@@ -3348,7 +3336,7 @@ extern "C" int lc3hip_destroy(void* ctx)
     if (c->d_pcm) hipFree(c->d_pcm);
     if (c->d_out) hipFree(c->d_out);
     if (c->d_dump) hipFree(c->d_dump);
-    for (int i = 0; i < LC3D_SETS; i++) { if (c->d_y12[i]) hipFree(c->d_y12[i]); if (c->d_d6[i]) hipFree(c->d_d6[i]); if (c->d_ol[i]) hipFree(c->d_ol[i]); }
+    for (int i = 0; i < LC3D_SETS; i++) if (c->d_y12[i]) hipFree(c->d_y12[i]);
     if (c->d_trace) hipFree(c->d_trace);
     if (c->d_status) hipFree(c->d_status);
     for (int i = 0; i < LC3D_SETS; i++) { if (c->d_spec[i]) hipFree(c->d_spec[i]); if (c->d_frec[i]) hipFree(c->d_frec[i]); }
