@@ -18,7 +18,7 @@ EXPORTS = [
     "lc3_enc_fl", "lc3_enc16", "lc3_enc24", "lc3_enc32", "lc3_enc_free_memory", "lc3_free_encoder_structs",
     "lc3plus_enc_batch_create", "lc3plus_enc_batch_destroy", "lc3plus_enc_batch_input_samples",
     "lc3plus_enc_batch_num_bytes", "lc3plus_enc_batch_stride", "lc3plus_enc_batch_set_bitrate",
-    "lc3plus_enc_batch_set_bandwidth", "lc3plus_enc_batch_encode", "lc3plus_enc_batch_last_kernel_ms", "lc3plus_enc_batch_last_status", "lc3plus_enc_batch_set_input_ready", "lc3plus_enc_batch_state_size", "lc3plus_enc_batch_get_state", "lc3plus_enc_batch_set_state",
+    "lc3plus_enc_batch_set_bandwidth", "lc3plus_enc_batch_encode", "lc3plus_enc_batch_last_kernel_ms", "lc3plus_enc_batch_last_status", "lc3plus_enc_batch_last_records", "lc3plus_enc_batch_record_words", "lc3plus_enc_batch_set_input_ready", "lc3plus_enc_batch_state_size", "lc3plus_enc_batch_get_state", "lc3plus_enc_batch_set_state",
     "lc3plus_dec_batch_state_size", "lc3plus_dec_batch_get_state", "lc3plus_dec_batch_set_state",
     "lc3plus_enc_init", "lc3plus_enc_set_frame_ms", "lc3plus_enc_set_hrmode", "lc3plus_enc_set_bitrate",
     "lc3plus_enc16", "lc3plus_enc_get_size",
@@ -59,6 +59,7 @@ def load_library():
         L.lc3plus_enc_batch_last_kernel_ms.restype = C.c_float
         L.lc3plus_enc_batch_last_kernel_ms.argtypes = [C.c_void_p]
         L.lc3plus_enc_batch_last_status.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        L.lc3plus_enc_batch_last_records.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         L.lc3plus_enc_batch_set_input_ready.argtypes = [C.c_void_p, C.c_int]
         for nm in ("lc3plus_enc_batch", "lc3plus_dec_batch"):
             getattr(L, nm + "_state_size").argtypes = [C.c_void_p]; getattr(L, nm + "_state_size").restype = C.c_size_t
@@ -167,6 +168,15 @@ class Batch:
         if n < 0:
             raise LC3Error(1, "lc3plus_enc_batch_last_status")
         return st
+
+    def last_records(self, T):
+        """float32 [n_streams * channels, T, words]: the per-frame records of the last call of the pipelined path (integer fields: .view(np.int32))."""
+        w = self.lib.lc3plus_enc_batch_record_words()
+        rec = np.zeros((self.n_streams * self.channels, T, w), dtype=np.float32)
+        n = self.lib.lc3plus_enc_batch_last_records(self.h, rec.ctypes.data, rec.size)
+        if n != rec.size:
+            raise LC3Error(1, "lc3plus_enc_batch_last_records (%d of %d words)" % (n, rec.size))
+        return rec
 
     def encode_traced(self, pcm, bitdepth=16):
         pcm = np.ascontiguousarray(pcm)

@@ -411,6 +411,12 @@ int lc3plus_enc_batch_last_status(lc3plus_batch* b, uint8_t* status, int max_ent
     if (!b || !status || max_entries < 0) return -1;
     return lc3hip_last_status(b->dev, status, max_entries);
 }
+int lc3plus_enc_batch_last_records(lc3plus_batch* b, float* records, int max_words)
+{
+    if (!b || !records || max_words < 0) return -1;
+    return lc3hip_last_records(b->dev, records, max_words);
+}
+int lc3plus_enc_batch_record_words(void) { return FR_WORDS; }
 
 size_t lc3plus_enc_batch_state_size(const lc3plus_batch* b) { return b ? lc3hip_state_bytes(b->dev) : 0; }
 LC3_Error lc3plus_enc_batch_get_state(lc3plus_batch* b, void* state, size_t size)

@@ -2906,7 +2906,7 @@ struct lc3hip_ctx {
     void* hp_dpcm[2]; void* hp_pin_in[2]; size_t hp_pcm_cap, hp_pin_in_cap;
     hipStream_t s_h2d; hipEvent_t ev_h2d[2], ev_k[2];
     hipStream_t s_pre, s_fr, s_pit, s_ln; hipEvent_t ev_fork, ev_p[LC3D_MAX_RUNS], ev_f[LC3D_MAX_RUNS], ev_h[LC3D_MAX_RUNS], ev_m[LC3D_MAX_RUNS];   /* side streams: pitch chain, frame-parallel front, frame-parallel tail */
-    int ylen, srow;
+    int ylen, srow; const float* last_frec; int last_frec_frames;      /* the records of the last pipelined call (lc3hip_last_records) */
     hipStream_t stream, last_stream; hipEvent_t ev0, ev1; float last_ms;
 };
 
@@ -3026,7 +3026,7 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
     float* rows_for_pack = nullptr; const float* frec_for_pack = nullptr;      /* pipelined path: the bitstream writer starts from the shaped spectra (frame-parallel tail, one frame per lane) */
     const int mc = c->big ? LC3D_MEMCAP_BIG : LC3D_MEMCAP_STD;
     if (!split) {
-        c->ahead_ok = 0;
+        c->ahead_ok = 0; c->last_frec = nullptr; c->last_frec_frames = 0;
         /* everything in lc3_encode_kernel (traced, diagnostic and very short launches), behind the 12.8 kHz pre-kernels when they apply */
         if (dy12) {
             const unsigned runs = (unsigned)((n_frames + PRE_FPW - 1) / PRE_FPW);
@@ -3066,6 +3066,7 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
         }
         float* dspec = c->d_spec[hb_]; float* dfrec = c->d_frec[hb_];
         rows_for_pack = dspec; frec_for_pack = dfrec;
+        c->last_frec = dfrec; c->last_frec_frames = dT;
         static int runf_env = -1;
         if (runf_env < 0) { const char* e = getenv("LC3PLUS_ENC_RUN_FRAMES"); runf_env = e && atoi(e) >= 1 ? atoi(e) : 0; }     /* diagnostic */
         const int runf = runf_env ? runf_env : c->input_ready ? LC3D_RUN_FRAMES_READY : LC3D_RUN_FRAMES;
@@ -3283,6 +3284,20 @@ extern "C" int lc3hip_last_status(void* ctx, uint8_t* status_host, int n)
     if (c->last_stream) HIPCHK(hipStreamSynchronize(c->last_stream));
     if (n > 0) HIPCHK(hipMemcpy(status_host, c->d_status, (size_t)n, hipMemcpyDeviceToHost));
     return n;
+}
+
+/* the per-frame records of the last call of the pipelined path (FR_* in lc3_plan.h: scale factors, SNS indices, bandwidth, LTPF and TNS parameters, gain floor,
+ * the rate kernel's four words), [channel-stream][frame][FR_WORDS] to host memory: stage-level parity tests of the product path read them */
+extern "C" int lc3hip_last_records(void* ctx, float* rec_host, int max_words)
+{
+    lc3hip_ctx* c = (lc3hip_ctx*)ctx;
+    if (!c || !c->last_frec) return 0;
+    HIPCHK(hipSetDevice(c->device));
+    if (c->last_stream) HIPCHK(hipStreamSynchronize(c->last_stream));
+    long long n = (long long)c->ncs * c->last_frec_frames * FR_WORDS;
+    if (n > max_words) n = max_words;
+    if (n > 0) HIPCHK(hipMemcpy(rec_host, c->last_frec, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    return (int)n;
 }
 
 /* checkpoint / resume: the cross-frame state of every channel-stream (LC3D_STATE_WORDS words each, the layout of lc3_plan.h) as one host

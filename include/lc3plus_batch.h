@@ -68,6 +68,15 @@ float lc3plus_enc_batch_last_kernel_ms(lc3plus_batch* batch);
  * returns the number of entries written (0 before the first call), negative on error.  Waits for the call to finish. */
 int lc3plus_enc_batch_last_status(lc3plus_batch* batch, uint8_t* status, int max_entries);
 
+/* Diagnostics: the per channel-frame records the kernels of the pipelined path hand to each other, of the last encode() call that took that path
+ * (calls of more than 8 frames; 0 words otherwise): host array [n_streams * channels][n_frames][lc3plus_enc_batch_record_words()] of 32-bit words
+ * - 16 scale factors, 16 quantised scale factors, 7 SNS indices, bandwidth index, attack-detector words, 4 LTPF words, 20 TNS words (filters,
+ * orders, bits, coefficient indices), gain floor, all-zero flag, bandwidth behind the controller, and gain index / gain / bit count / last
+ * non-zero line of the first quantisation (layout: FR_* in audio_codec_amd/csrc/lc3_plan.h).  The stage-level parity tests compare them with the
+ * reference restatement's trace of the same frames.  Returns the words written, negative on error.  Waits for the call to finish. */
+int lc3plus_enc_batch_last_records(lc3plus_batch* batch, float* records, int max_words);
+int lc3plus_enc_batch_record_words(void);
+
 /* ---- batched decoder: n_streams independent decoder instances, one wavefront per channel-stream; same
  * conventions as the encoder batch.  num_bytes[n_streams] = bytes per stream-frame (all channels; may be NULL
  * and set later per stream).  R/dec_lc3_fl.c:134-163 is what one (stream, frame) does. ---- */

@@ -717,3 +717,47 @@ def test_full_size_baseline_batch_properties():
         c = 10 * np.log10(np.maximum(s, 1e-9) / np.maximum(e, 1e-9))
         best = c if c.mean() > best.mean() else best
     assert np.median(best) > 12.0, np.median(best)
+
+
+@pytest.mark.parametrize("fs,ms,hr,N,br", [(48000, 10.0, 0, 480, 64000), (48000, 10.0, 0, 480, 24000), (32000, 5.0, 0, 160, 64000), (16000, 2.5, 0, 40, 96000),
+                                           (96000, 2.5, 1, 240, 256000), (96000, 10.0, 1, 960, 256000)])
+def test_pipelined_path_records_match_oracle(fs, ms, hr, N, br):
+    """Stage by stage on the PRODUCT path (the pipelined kernels, not the traced whole-encoder kernel): the per-frame records the kernels hand to each other
+    (lc3plus_enc_batch_last_records) against the oracle's trace of the same frames - scale factors (lc3_enc_scf_lane_kernel), quantised scale factors and SNS
+    indices (lc3_enc_snsvq_kernel), LTPF words (lc3_enc_pitch_kernel), bandwidth, TNS filters / orders / bits / coefficient indices, gain floor
+    (lc3_enc_shape_lane_kernel), gain index, gain and bit count of the first quantisation (lc3_enc_rate_kernel); floats bit for bit."""
+    amd = _amd()
+    FR = dict(SCF=0, SCFQ=16, IDX=32, LTPF=48, TNS=52, GGMIN=72, XZERO=73, BWC=74, RATE=76)
+    B, T = 5, 12                                               # 12 frames: the pipelined path
+    pcm = synth_pcm(B, T, N, fs, seed=41)
+    bt = amd.Batch(B, fs, 1, ms, hr, [br] * B, device=0)
+    got = bt.encode(pcm)
+    rec = bt.last_records(T)
+    ri = rec.view(np.int32)
+    nb = bt.num_bytes(0)
+    bad = []
+    for b in range(B):
+        o = Oracle(fs, 1, ms, hr, br, portable_math=True)
+        tr = o.enable_trace()
+        for t in range(T):
+            want = o.encode(pcm[b, t][None])
+            assert (got[b, t, :nb] == want).all(), (b, t)
+            w = tr[0]
+            def chk(name, a, c):
+                a, c = np.asarray(a), np.asarray(c)
+                same = (a.view(np.uint32) == c.view(np.uint32)) | ((a == 0) & (c == 0)) if a.dtype.kind == "f" else (a == c)
+                if not np.all(same): bad.append((b, t, name))
+            if not w.attack:                                   # with the attack flag the record keeps the unsmoothed factors (the quantiser's kernel smooths them)
+                chk("scf", rec[b, t, FR["SCF"]:FR["SCF"] + 16], np.ctypeslib.as_array(w.scf).astype(np.float32))
+            chk("scf_q", rec[b, t, FR["SCFQ"]:FR["SCFQ"] + 16], np.ctypeslib.as_array(w.scf_q).astype(np.float32))
+            chk("scf_idx", ri[b, t, FR["IDX"]:FR["IDX"] + 7], np.ctypeslib.as_array(w.scf_idx))
+            chk("ltpf", ri[b, t, FR["LTPF"]:FR["LTPF"] + 4], np.array([w.ltpf_param[0], w.ltpf_param[1], w.ltpf_param[2], w.ltpf_bits]))
+            chk("bw", ri[b, t, FR["BWC"]:FR["BWC"] + 1], np.array([w.bw_idx]))
+            chk("tns", ri[b, t, FR["TNS"]:FR["TNS"] + 4], np.array([w.tns_nfilt, w.tns_order[0], w.tns_order[1], w.tns_bits]))
+            chk("tns_idx", ri[b, t, FR["TNS"] + 4:FR["TNS"] + 20], np.ctypeslib.as_array(w.tns_rc_idx))
+            chk("gg_min", np.array([int(rec[b, t, FR["GGMIN"]])]), np.array([w.gg_min]))
+            chk("gg_idx0", ri[b, t, FR["RATE"]:FR["RATE"] + 1], np.array([w.gg_idx0]))
+            chk("gain0", rec[b, t, FR["RATE"] + 1:FR["RATE"] + 2], np.array([w.gain0], np.float32))
+            chk("nbits0", ri[b, t, FR["RATE"] + 2:FR["RATE"] + 3], np.array([w.nbits0]))
+    assert not bad, bad[:12]
+    bt.close()
