@@ -698,23 +698,22 @@ template <class LdsT> STAGE void st_ltpf(const lc3d_plan* __restrict__ P, const 
 /* ---- attack detector: R/attack_detector.c:13-104 (only when attack_handling) ---- */
 /* first half (:26-77): decimation to 16 kHz, high-pass with the filter memory (m0, m1) of the previous frame, block energies: lane b < nb
  * returns block b's energy; (nm0, nm1) is the filter memory this frame leaves.  Stateless given the previous frame's last samples. */
-template <class LdsT> __device__ __forceinline__ float attack_energies(LdsT& L, int lane, float m0, float m1, float& nm0, float& nm1)
+__device__ __forceinline__ float attack_energies_at(const int nb, const int fs_hz, const float* in /* the frame's PCM */, float* scr /* 362 floats of scratch */, int lane, float m0, float m1, float& nm0, float& nm1)
 {
-    const int nb = PI(att_nblocks), n16 = nb * 40;
-    const float* in = XCUR(L);
-    float* p = &L.A[2];
+    const int n16 = nb * 40;
+    float* p = &scr[2];
     for (int j = lane; j < n16; j += WAVE) {
         float v;
-        if (PI(fs) == 96000) { const float* q = &in[6 * j]; v = q[0] + q[1] + q[2] + q[3] + q[4] + q[5]; }
-        else if (PI(fs) == 48000) { const float* q = &in[3 * j]; v = (q[0] + q[1] + q[2]); }
-        else if (PI(fs) == 32000) { const float* q = &in[2 * j]; v = (q[0] + q[1]); }
+        if (fs_hz == 96000) { const float* q = &in[6 * j]; v = q[0] + q[1] + q[2] + q[3] + q[4] + q[5]; }
+        else if (fs_hz == 48000) { const float* q = &in[3 * j]; v = (q[0] + q[1] + q[2]); }
+        else if (fs_hz == 32000) { const float* q = &in[2 * j]; v = (q[0] + q[1]); }
         else { const float* q = &in[3 * j]; v = (float)((double)q[0] + ((double)(q[1] + q[2])) / 2.0); }
         p[j] = v;
     }
     if (lane == 0) { p[-2] = m0; p[-1] = m1; }
     LSYNC();
     nm0 = p[n16 - 2]; nm1 = p[n16 - 1];
-    float* fs = &L.A[200];
+    float* fs = &scr[200];
     for (int i = lane; i < 160; i += WAVE) {
         float t = 0;
         t = (float)((double)t + (double)p[i] * 0.375);
@@ -726,6 +725,10 @@ template <class LdsT> __device__ __forceinline__ float attack_energies(LdsT& L, 
     float e = 0;
     if (lane < nb) { for (int k = 0; k < 40; k++) { const float v = fs[k + lane * 40]; e += v * v; } }
     return e;
+}
+template <class LdsT> __device__ __forceinline__ float attack_energies(LdsT& L, int lane, float m0, float m1, float& nm0, float& nm1)
+{
+    return attack_energies_at(PI(att_nblocks), PI(fs), XCUR(L), L.A, lane, m0, m1, nm0, nm1);
 }
 /* second half (:79-102): the decision over the blocks, sequential from frame to frame through (acc, last position) */
 __device__ __forceinline__ void attack_decide(float e0, float e1, float e2, float e3, int nb, float mval, int hang, float& acc, int& last_pos, int& flag)
@@ -2868,6 +2871,9 @@ KERNEL_NAME(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans
 /* C-ABI device shim (lc3_shim.h): context, uploads, launch                                          */
 /* ------------------------------------------------------------------------------------------------ */
 #include "lc3_enc_front.inc"       /* lc3_enc_front_kernel (or _big): the stateless front, frame-parallel */
+#ifndef LC3_BIG
+#include "lc3_enc_front4.inc"      /* lc3_enc_front4_kernel: the same for N = 480, four frames per wave */
+#endif
 #include "lc3_enc_seq.inc"         /* lc3_enc_pitch_kernel: the pitch chain of the pipelined path */
 #include "lc3_enc_rate.inc"        /* lc3_enc_shape_kernel, lc3_enc_rate_kernel, lc3_enc_tail_kernel (or _big): the rate chain and its frame-parallel neighbours */
 #include "lc3_dec_kernels.inc"     /* lc3_dec_{plc,imdct,synth}_kernel, or the _big imdct / synth kernels in the large-layout object */
@@ -2906,7 +2912,7 @@ struct lc3hip_ctx {
     void* hp_dpcm[2]; void* hp_pin_in[2]; size_t hp_pcm_cap, hp_pin_in_cap;
     hipStream_t s_h2d; hipEvent_t ev_h2d[2], ev_k[2];
     hipStream_t s_pre, s_fr, s_pit, s_ln; hipEvent_t ev_fork, ev_p[LC3D_MAX_RUNS], ev_f[LC3D_MAX_RUNS], ev_h[LC3D_MAX_RUNS], ev_m[LC3D_MAX_RUNS];   /* side streams: pitch chain, frame-parallel front, frame-parallel tail */
-    int ylen, srow; const float* last_frec; int last_frec_frames;      /* the records of the last pipelined call (lc3hip_last_records) */
+    int ylen, srow, la; const float* last_frec; int last_frec_frames;      /* the records of the last pipelined call (lc3hip_last_records) */
     hipStream_t stream, last_stream; hipEvent_t ev0, ev1; float last_ms;
 };
 
@@ -2929,7 +2935,7 @@ extern "C" int lc3hip_create(void** out_ctx, const lc3d_plan* plan, int n_stream
     HIPCHK_OR(hipSetDevice(device), free(c));
     c->n_streams = n_streams; c->channels = plan->channels; c->ncs = n_streams * plan->channels; c->N = plan->N;
     c->big = LC3D_LAYOUT_BIG(plan->N, plan->la);
-    c->hr = plan->hrmode; c->ylen = plan->ylen; c->srow = LC3D_SROW(plan->ylen);
+    c->hr = plan->hrmode; c->ylen = plan->ylen; c->la = plan->la; c->srow = LC3D_SROW(plan->ylen);
     { const char* e = getenv("LC3PLUS_ENC_FUSED"); c->fused = e && e[0] == '1'; }     /* diagnostic: the bitstream writer inside lc3_encode_kernel */
     c->state_words = LC3D_STATE_WORDS(c->big ? LC3D_MEMCAP_BIG : LC3D_MEMCAP_STD);
     HIPCHK_OR(hipMalloc((void**)&c->d_plan, sizeof(lc3d_plan)), lc3hip_destroy(c));
@@ -3124,7 +3130,11 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
             if (scf_wave < 0) { const char* e = getenv("LC3PLUS_ENC_SCF_WAVE"); scf_wave = e && e[0] == '1'; }     /* diagnostic: energies / scale factors in the front kernel */
             const int fpw = nt < FRONT_FPW ? nt : FRONT_FPW;
             const unsigned fruns = (unsigned)((nt + fpw - 1) / fpw);
-            if (c->big) hipLaunchKernelGGL(lc3_enc_front_kernel_big, dim3((unsigned)c->ncs * fruns), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames, tb, nt, fpw, c->ncs, dspec, c->srow, dT, dt0, dfrec, xn_w, xprev, xprev_stride, scf_wave);
+            static int f4 = -1;
+            if (f4 < 0) { const char* e = getenv("LC3PLUS_ENC_FRONT4"); f4 = !(e && e[0] == '0'); }     /* diagnostic: 0 = the one-frame-at-a-time kernel for N = 480 too */
+            if (f4 && !c->big && !scf_wave && c->N == 480 && c->la == 180 && (c->ylen & 15) == 0)
+                DUPL('f') hipLaunchKernelGGL(lc3_enc_front4_kernel, dim3((unsigned)c->ncs * (unsigned)((nt + 3) / 4)), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames, tb, nt, c->ncs, dspec, c->srow, dT, dt0, dfrec, xn_w, xprev, xprev_stride);
+            else if (c->big) hipLaunchKernelGGL(lc3_enc_front_kernel_big, dim3((unsigned)c->ncs * fruns), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames, tb, nt, fpw, c->ncs, dspec, c->srow, dT, dt0, dfrec, xn_w, xprev, xprev_stride, scf_wave);
             else DUPL('f') hipLaunchKernelGGL(lc3_enc_front_kernel, dim3((unsigned)c->ncs * fruns), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames, tb, nt, fpw, c->ncs, dspec, c->srow, dT, dt0, dfrec, xn_w, xprev, xprev_stride, scf_wave);
             HIPCHK(hipEventRecord(c->ev_m[k], c->s_fr));                 /* the MDCT memory hand-over and the spectrum rows of the run are written */
             if (five) HIPCHK(hipStreamWaitEvent(c->s_ln, c->ev_m[k], 0));
