@@ -2873,6 +2873,7 @@ KERNEL_NAME(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans
 #include "lc3_enc_front.inc"       /* lc3_enc_front_kernel (or _big): the stateless front, frame-parallel */
 #ifndef LC3_BIG
 #include "lc3_enc_front4.inc"      /* lc3_enc_front4_kernel: the same for N = 480, four frames per wave */
+#include "lc3_enc_pitch2.inc"      /* lc3_enc_pitch2_kernel: the pitch chain, two streams per wave */
 #endif
 #include "lc3_enc_seq.inc"         /* lc3_enc_pitch_kernel: the pitch chain of the pipelined path */
 #include "lc3_enc_rate.inc"        /* lc3_enc_shape_kernel, lc3_enc_rate_kernel, lc3_enc_tail_kernel (or _big): the rate chain and its frame-parallel neighbours */
@@ -3123,7 +3124,10 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
                 hb += hn; hk++;
                 if (five) { HIPCHK(hipEventRecord(c->ev_h[k], c->s_pre)); HIPCHK(hipStreamWaitEvent(c->s_pit, c->ev_h[k], 0)); }
             }
-            DUPL('p') hipLaunchKernelGGL(lc3_enc_pitch_kernel, dim3(c->ncs), dim3(WAVE), 0, c->s_pit, c->d_plan, c->d_chans, c->d_state, c->state_words, mc, dy12, n_frames, tb, nt, c->ncs, dfrec, dT, dt0);
+            static int p2 = -1;
+            if (p2 < 0) { const char* e = getenv("LC3PLUS_ENC_PITCH2"); p2 = !(e && e[0] == '0'); }     /* diagnostic: 0 = one stream per wave */
+            if (p2) DUPL('p') hipLaunchKernelGGL(lc3_enc_pitch2_kernel, dim3((unsigned)((c->ncs + 1) / 2)), dim3(WAVE), 0, c->s_pit, c->d_plan, c->d_chans, c->d_state, c->state_words, mc, dy12, n_frames, tb, nt, c->ncs, dfrec, dT, dt0);
+            else DUPL('p') hipLaunchKernelGGL(lc3_enc_pitch_kernel, dim3(c->ncs), dim3(WAVE), 0, c->s_pit, c->d_plan, c->d_chans, c->d_state, c->state_words, mc, dy12, n_frames, tb, nt, c->ncs, dfrec, dT, dt0);
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(c->ev_p[k], c->s_pit));
             static int scf_wave = -1;
