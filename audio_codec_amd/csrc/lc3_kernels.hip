@@ -2913,7 +2913,7 @@ struct lc3hip_ctx {
     void* hp_dpcm[2]; void* hp_pin_in[2]; size_t hp_pcm_cap, hp_pin_in_cap;
     hipStream_t s_h2d; hipEvent_t ev_h2d[2], ev_k[2];
     hipStream_t s_pre, s_fr, s_pit, s_ln; hipEvent_t ev_fork, ev_p[LC3D_MAX_RUNS], ev_f[LC3D_MAX_RUNS], ev_h[LC3D_MAX_RUNS], ev_m[LC3D_MAX_RUNS];   /* side streams: pitch chain, frame-parallel front, frame-parallel tail */
-    int ylen, srow, la; const float* last_frec; int last_frec_frames;      /* the records of the last pipelined call (lc3hip_last_records) */
+    int ylen, srow, la, len12; const float* last_frec; int last_frec_frames;      /* the records of the last pipelined call (lc3hip_last_records) */
     hipStream_t stream, last_stream; hipEvent_t ev0, ev1; float last_ms;
 };
 
@@ -2936,7 +2936,7 @@ extern "C" int lc3hip_create(void** out_ctx, const lc3d_plan* plan, int n_stream
     HIPCHK_OR(hipSetDevice(device), free(c));
     c->n_streams = n_streams; c->channels = plan->channels; c->ncs = n_streams * plan->channels; c->N = plan->N;
     c->big = LC3D_LAYOUT_BIG(plan->N, plan->la);
-    c->hr = plan->hrmode; c->ylen = plan->ylen; c->la = plan->la; c->srow = LC3D_SROW(plan->ylen);
+    c->hr = plan->hrmode; c->ylen = plan->ylen; c->la = plan->la; c->len12 = plan->len12; c->srow = LC3D_SROW(plan->ylen);
     { const char* e = getenv("LC3PLUS_ENC_FUSED"); c->fused = e && e[0] == '1'; }     /* diagnostic: the bitstream writer inside lc3_encode_kernel */
     c->state_words = LC3D_STATE_WORDS(c->big ? LC3D_MEMCAP_BIG : LC3D_MEMCAP_STD);
     HIPCHK_OR(hipMalloc((void**)&c->d_plan, sizeof(lc3d_plan)), lc3hip_destroy(c));
@@ -3126,7 +3126,10 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
             }
             static int p2 = -1;
             if (p2 < 0) { const char* e = getenv("LC3PLUS_ENC_PITCH2"); p2 = !(e && e[0] == '0'); }     /* diagnostic: 0 = one stream per wave */
-            if (p2) DUPL('p') hipLaunchKernelGGL(lc3_enc_pitch2_kernel, dim3((unsigned)((c->ncs + 1) / 2)), dim3(WAVE), 0, c->s_pit, c->d_plan, c->d_chans, c->d_state, c->state_words, mc, dy12, n_frames, tb, nt, c->ncs, dfrec, dT, dt0);
+            if (p2 && (c->len12 == 128 || c->len12 == 64 || c->len12 == 32)) {
+                auto pk = c->len12 == 128 ? lc3_enc_pitch2_kernel : c->len12 == 64 ? lc3_enc_pitch2_kernel_l64 : lc3_enc_pitch2_kernel_l32;
+                DUPL('p') hipLaunchKernelGGL(pk, dim3((unsigned)((c->ncs + 1) / 2)), dim3(WAVE), 0, c->s_pit, c->d_plan, c->d_chans, c->d_state, c->state_words, mc, dy12, n_frames, tb, nt, c->ncs, dfrec, dT, dt0);
+            }
             else DUPL('p') hipLaunchKernelGGL(lc3_enc_pitch_kernel, dim3(c->ncs), dim3(WAVE), 0, c->s_pit, c->d_plan, c->d_chans, c->d_state, c->state_words, mc, dy12, n_frames, tb, nt, c->ncs, dfrec, dT, dt0);
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(c->ev_p[k], c->s_pit));
