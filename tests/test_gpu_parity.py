@@ -761,3 +761,32 @@ def test_pipelined_path_records_match_oracle(fs, ms, hr, N, br):
             chk("nbits0", ri[b, t, FR["RATE"] + 2:FR["RATE"] + 3], np.array([w.nbits0]))
     assert not bad, bad[:12]
     bt.close()
+
+
+@pytest.mark.parametrize("B,T,off", [(33, 13, 0), (7, 22, 2), (65, 9, 6)])
+def test_odd_stream_counts_and_unaligned_pcm_on_the_pipelined_path(B, T, off):
+    """The four-frames-per-wave front kernel and the two-streams-per-wave pitch kernel at their edges: an odd number of channel-streams (the
+    last pitch wave's second half shadows the last stream), frame counts that are not multiples of four (a wave's last run is short), and a
+    PCM pointer that is not 16-byte aligned (the front and resampler kernels fall back from 128-bit loads), two calls so that state runs on."""
+    amd = _amd()
+    d = _Dev()
+    try:
+        rates = [64000, 128000, 32000]
+        br = [rates[i % 3] for i in range(B)]
+        pcm = synth_pcm(B, 2 * T, 480, 48000, seed=4242 + B)
+        b = amd.Batch(B, 48000, 1, 10.0, 0, br, device=0)
+        stride = b.stride
+        outs = []
+        for h in range(2):
+            raw = np.zeros(off + B * T * 480 * 2 + 16, np.uint8)
+            raw[off:off + B * T * 480 * 2] = np.ascontiguousarray(pcm[:, h * T:(h + 1) * T]).view(np.uint8).reshape(-1)
+            pin = d.put(raw); pout = d.zeros(B * T * stride)
+            b.encode_device(pin + off, 16, T, pout, stride, hip_stream=None, sync=True)
+            outs.append(d.get(pout, (B, T, stride), np.uint8))
+        got = np.concatenate(outs, axis=1)
+        want = _oracle_batch(pcm, 48000, 10.0, 0, br, stride)
+        nb = [b.num_bytes(i) for i in range(B)]
+        bad = [(i, t) for i in range(B) for t in range(2 * T) if (got[i, t, :nb[i]] != want[i, t, :nb[i]]).any()]
+        assert not bad, (len(bad), bad[:8])
+    finally:
+        d.free()
