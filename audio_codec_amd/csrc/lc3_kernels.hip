@@ -2896,7 +2896,9 @@ extern "C" __global__ void lc3_enc_rate_kernel_big(const lc3d_plan* __restrict__
 #include "lc3_enc_shapel.inc"
 #include "lc3_enc_pre.inc"
 #define LC3D_MAX_RUNS 16
+#ifndef LC3D_SETS
 #define LC3D_SETS 3                     /* sets of hand-over buffers under the input-ready promise: that many calls may be in flight */
+#endif
 #define LC3D_AHEAD_MAX_FRAMES 256     /* lc3hip_set_input_ready: calls of up to this many frames overlap with their predecessor */
 #define LC3D_RUN_FRAMES 16            /* frames per run when consecutive calls do not overlap (measured, 4096 streams x 64 frames: 8: 58.1, 16: 64.9, 32: 62.8, 64: 58.6 Mframes/s) */
 #define LC3D_RUN_FRAMES_READY 64      /* under the input-ready promise (calls overlap, a call's own pipeline matters less: 8: 62.4, 16: 70.1, 32: 72.6, 64: 73.0) */
@@ -2912,7 +2914,7 @@ struct lc3hip_ctx {
     /* host-pointer pipeline (lc3hip_encode_host): two chunk slots, each with device staging and (for pageable callers) pinned staging */
     void* hp_dpcm[2]; void* hp_pin_in[2]; size_t hp_pcm_cap, hp_pin_in_cap;
     hipStream_t s_h2d; hipEvent_t ev_h2d[2], ev_k[2];
-    hipStream_t s_pre, s_fr, s_pit, s_ln; hipEvent_t ev_fork, ev_p[LC3D_MAX_RUNS], ev_f[LC3D_MAX_RUNS], ev_h[LC3D_MAX_RUNS], ev_m[LC3D_MAX_RUNS];   /* side streams: pitch chain, frame-parallel front, frame-parallel tail */
+    hipStream_t s_pre, s_fr, s_pit, s_ln, s_rt; hipEvent_t ev_rate; hipEvent_t ev_fork, ev_p[LC3D_MAX_RUNS], ev_f[LC3D_MAX_RUNS], ev_h[LC3D_MAX_RUNS], ev_m[LC3D_MAX_RUNS];   /* side streams: pitch chain, frame-parallel front, frame-parallel tail */
     int ylen, srow, la, len12; const float* last_frec; int last_frec_frames;      /* the records of the last pipelined call (lc3hip_last_records) */
     hipStream_t stream, last_stream; hipEvent_t ev0, ev1; float last_ms;
 };
@@ -3067,6 +3069,13 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
             { const char* e = getenv("LC3PLUS_ENC_STREAMS"); c->s_pit = c->s_pre; c->s_ln = c->s_fr;
               if (e && atoi(e) >= 5) { HIPCHK(hipStreamCreateWithFlags(&c->s_pit, hipStreamNonBlocking)); HIPCHK(hipStreamCreateWithFlags(&c->s_ln, hipStreamNonBlocking)); } }
             for (int i = 0; i < LC3D_MAX_RUNS; i++) { HIPCHK(hipEventCreateWithFlags(&c->ev_h[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_m[i], hipEventDisableTiming)); }
+            /* LC3PLUS_ENC_RATE_STREAM=1 (diagnostic): the rate chain on a stream of its own, so that the rate kernel of call k+1 runs beside the bitstream
+             * writer of call k (which stays on the caller's stream: it is what the caller waits for).  Measured: calls of 16 frames (c3) +5 %, calls of 64
+             * frames (c1) 0 ... -11 % - a fourth side stream shares one of HIP's four hardware queues with another one, depending on what else the
+             * process created: off by default */
+            { const char* e = getenv("LC3PLUS_ENC_RATE_STREAM"); c->s_rt = NULL;
+              if (e && e[0] == '1') HIPCHK(hipStreamCreateWithFlags(&c->s_rt, hipStreamNonBlocking)); }
+            HIPCHK(hipEventCreateWithFlags(&c->ev_rate, hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
             for (int i = 0; i < LC3D_SETS; i++) HIPCHK(hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming));
             for (int i = 0; i < LC3D_MAX_RUNS; i++) { HIPCHK(hipEventCreateWithFlags(&c->ev_p[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_f[i], hipEventDisableTiming)); }
@@ -3100,7 +3109,9 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
         if (!ahead) {
             HIPCHK(hipEventRecord(c->ev_fork, s)); HIPCHK(hipStreamWaitEvent(c->s_pre, c->ev_fork, 0)); HIPCHK(hipStreamWaitEvent(c->s_fr, c->ev_fork, 0));
             if (five) { HIPCHK(hipStreamWaitEvent(c->s_pit, c->ev_fork, 0)); HIPCHK(hipStreamWaitEvent(c->s_ln, c->ev_fork, 0)); }
+            if (c->s_rt) HIPCHK(hipStreamWaitEvent(c->s_rt, c->ev_fork, 0));
         } else {
+            if (c->s_rt) HIPCHK(hipStreamWaitEvent(c->s_rt, c->ev_done[hb_], 0));       /* the records the rate kernel writes were last read by that writer */
             HIPCHK(hipStreamWaitEvent(c->s_pre, c->ev_m[R - 1], 0));    /* the resampler reads the hand-over the previous call's last front kernel wrote */
             HIPCHK(hipStreamWaitEvent(c->s_pre, c->ev_done[hb_], 0)); HIPCHK(hipStreamWaitEvent(c->s_fr, c->ev_done[hb_], 0));
             if (five) { HIPCHK(hipStreamWaitEvent(c->s_pit, c->ev_done[hb_], 0)); HIPCHK(hipStreamWaitEvent(c->s_ln, c->ev_done[hb_], 0));
@@ -3111,6 +3122,7 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
          * kernel should start early), then three runs at a time, in stream order between the pitch kernels that need them.  (More side
          * streams than these two do not help: HIP multiplexes streams onto a few hardware queues and kernels of two streams that share
          * one run back to back.) */
+        hipStream_t rs = s;                                  /* where the rate kernels run */
         for (int k = 0, tb = 0, hb = 0, hk = 0; tb < n_frames; k++, tb += Tr) {
             const int nt = n_frames - tb < Tr ? n_frames - tb : Tr;
             if (tb >= hb) {
@@ -3158,6 +3170,7 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
                 const int spw = nt < sfpw ? nt : sfpw;
                 const unsigned sruns = (unsigned)((nt + spw - 1) / spw);
                 hipStream_t ss = son ? s : c->s_ln;
+                rs = (son || !c->s_rt) ? s : c->s_rt;
                 if (son) { HIPCHK(hipEventRecord(c->ev_f[k], c->s_ln)); HIPCHK(hipStreamWaitEvent(s, c->ev_f[k], 0)); }
                 static int swave = -1;
                 if (swave < 0) { const char* e = getenv("LC3PLUS_ENC_SHAPE_WAVE"); swave = e && e[0] == '1'; }     /* diagnostic: the wave-per-frame kernel */
@@ -3165,14 +3178,15 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
                 else if (c->big) hipLaunchKernelGGL(lc3_enc_shape_kernel_big, dim3((unsigned)c->ncs * sruns), dim3(WAVE), 0, ss, c->d_plan, c->d_chans, dT, dt0 + tb, nt, spw, c->ncs, dspec, c->srow, dfrec);
                 else DUPL('a') hipLaunchKernelGGL(lc3_enc_shape_kernel, dim3((unsigned)c->ncs * sruns), dim3(WAVE), 0, ss, c->d_plan, c->d_chans, dT, dt0 + tb, nt, spw, c->ncs, dspec, c->srow, dfrec);
                 HIPCHK(hipGetLastError());
-                if (!son) { HIPCHK(hipEventRecord(c->ev_f[k], c->s_ln)); HIPCHK(hipStreamWaitEvent(s, c->ev_f[k], 0)); }
+                if (!son) { HIPCHK(hipEventRecord(c->ev_f[k], c->s_ln)); HIPCHK(hipStreamWaitEvent(rs, c->ev_f[k], 0)); }
             }
-            HIPCHK(hipStreamWaitEvent(s, c->ev_p[k], 0));
+            HIPCHK(hipStreamWaitEvent(rs, c->ev_p[k], 0));
             const int last = tb + nt >= n_frames;            /* behind the last frame of this launch the MDCT memory goes into the state */
-            if (c->big) hipLaunchKernelGGL(lc3_enc_rate_kernel_big, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, dT, dt0 + tb, nt, c->ncs, dspec, c->srow, dfrec, xn_w, last);
-            else DUPL('s') hipLaunchKernelGGL(lc3_enc_rate_kernel, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, dT, dt0 + tb, nt, c->ncs, dspec, c->srow, dfrec, xn_w, last);
+            if (c->big) hipLaunchKernelGGL(lc3_enc_rate_kernel_big, dim3(c->ncs), dim3(WAVE), 0, rs, c->d_plan, c->d_chans, c->d_state, dT, dt0 + tb, nt, c->ncs, dspec, c->srow, dfrec, xn_w, last);
+            else DUPL('s') hipLaunchKernelGGL(lc3_enc_rate_kernel, dim3(c->ncs), dim3(WAVE), 0, rs, c->d_plan, c->d_chans, c->d_state, dT, dt0 + tb, nt, c->ncs, dspec, c->srow, dfrec, xn_w, last);
             HIPCHK(hipGetLastError());
         }
+        if (rs != s) { HIPCHK(hipEventRecord(c->ev_rate, rs)); HIPCHK(hipStreamWaitEvent(s, c->ev_rate, 0)); }      /* the writer (and whatever the caller queues next) behind the rate chain */
         c->ahead_ok = (dt0 == 0 && dT == n_frames && pack) ? 1 : 0; c->ahead_T = n_frames; c->ahead_R = R;
         c->xn_par = (c->xn_par + 1) % (LC3D_SETS + 1);
     }
@@ -3381,7 +3395,7 @@ extern "C" int lc3hip_destroy(void* ctx)
         if (c->ev_k[i]) hipEventDestroy(c->ev_k[i]);
     }
     if (c->s_h2d) hipStreamDestroy(c->s_h2d);
-    if (c->s_pre) { if (c->s_pit != c->s_pre) { hipStreamDestroy(c->s_pit); hipStreamDestroy(c->s_ln); } hipStreamDestroy(c->s_pre); hipStreamDestroy(c->s_fr);
+    if (c->s_pre) { if (c->s_pit != c->s_pre) { hipStreamDestroy(c->s_pit); hipStreamDestroy(c->s_ln); } hipStreamDestroy(c->s_pre); hipStreamDestroy(c->s_fr); if (c->s_rt) hipStreamDestroy(c->s_rt); hipEventDestroy(c->ev_rate);
                     for (int i = 0; i < LC3D_MAX_RUNS; i++) { hipEventDestroy(c->ev_h[i]); hipEventDestroy(c->ev_m[i]); } hipEventDestroy(c->ev_fork); for (int i = 0; i < LC3D_SETS; i++) hipEventDestroy(c->ev_done[i]);
                     for (int i = 0; i < LC3D_MAX_RUNS; i++) { hipEventDestroy(c->ev_p[i]); hipEventDestroy(c->ev_f[i]); } }
     if (c->ev0) hipEventDestroy(c->ev0);
