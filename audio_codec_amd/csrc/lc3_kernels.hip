@@ -3182,8 +3182,8 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
             }
             HIPCHK(hipStreamWaitEvent(rs, c->ev_p[k], 0));
             const int last = tb + nt >= n_frames;            /* behind the last frame of this launch the MDCT memory goes into the state */
-            if (c->big) hipLaunchKernelGGL(lc3_enc_rate_kernel_big, dim3(c->ncs), dim3(WAVE), 0, rs, c->d_plan, c->d_chans, c->d_state, dT, dt0 + tb, nt, c->ncs, dspec, c->srow, dfrec, xn_w, last);
-            else DUPL('s') hipLaunchKernelGGL(lc3_enc_rate_kernel, dim3(c->ncs), dim3(WAVE), 0, rs, c->d_plan, c->d_chans, c->d_state, dT, dt0 + tb, nt, c->ncs, dspec, c->srow, dfrec, xn_w, last);
+            if (c->big) hipLaunchKernelGGL(lc3_enc_rate_kernel_big, dim3((unsigned)((c->ncs + RATE_WG - 1) / RATE_WG)), dim3(RATE_WG * WAVE), 0, rs, c->d_plan, c->d_chans, c->d_state, dT, dt0 + tb, nt, c->ncs, dspec, c->srow, dfrec, xn_w, last);
+            else DUPL('s') hipLaunchKernelGGL(lc3_enc_rate_kernel, dim3((unsigned)((c->ncs + RATE_WG - 1) / RATE_WG)), dim3(RATE_WG * WAVE), 0, rs, c->d_plan, c->d_chans, c->d_state, dT, dt0 + tb, nt, c->ncs, dspec, c->srow, dfrec, xn_w, last);
             HIPCHK(hipGetLastError());
         }
         if (rs != s) { HIPCHK(hipEventRecord(c->ev_rate, rs)); HIPCHK(hipStreamWaitEvent(s, c->ev_rate, 0)); }      /* the writer (and whatever the caller queues next) behind the rate chain */
