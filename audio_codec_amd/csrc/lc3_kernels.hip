@@ -3192,7 +3192,8 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
     }
     if (ddump && pack) {
         HIPCHK(hipGetLastError());
-        const int wpg = 4;
+        static int wpg = 0;                               /* waves per workgroup of the writer (they share the coder's tables in LDS) */
+        if (!wpg) { const char* e = getenv("LC3PLUS_ENC_PACK_WPG"); wpg = e && atoi(e) >= 1 && atoi(e) <= 4 ? atoi(e) : 4; }     /* diagnostic */
         const size_t per_wave = (size_t)PK_XBUF * WAVE * sizeof(unsigned);
         const long long tasks = (long long)c->ncs * dT, per_wg = (long long)wpg * WAVE;
         DUPL('k') hipLaunchKernelGGL(lc3_enc_pack_kernel, dim3((unsigned)((tasks + per_wg - 1) / per_wg)), dim3(wpg * WAVE), per_wave * wpg, s, c->d_plan, c->d_chans, ddump, dstride,
