@@ -320,7 +320,7 @@ def main():
         achieved = algo / (kern_ms * 1e-3) / 1e9
         prof = committed_profile(a.workload, B, T)
         kernels = ("lc3_dec_parse_kernel + lc3_dec_plc_kernel + lc3_dec_imdct_kernel + lc3_dec_synth_kernel" if decode else
-                   "lc3_enc_resample/hp50/pitch_kernel (pitch chain) || lc3_enc_front_kernel (MDCT, wave per frame) -> lc3_enc_scf_lane/attack/snsvq/shape_lane_kernel "
+                   "lc3_enc_resample/hp50/pitch2_kernel (pitch chain, two streams per wave) || lc3_enc_front4_kernel (MDCT, four frames per wave) -> lc3_enc_scf_lane/attack/snsvq/shape_lane_kernel "
                    "(one frame per lane) -> lc3_enc_rate_kernel (rate chain, wave per stream) -> lc3_enc_pack_kernel (tail + bitstream writer, one frame per lane); "
                    "three HIP streams, up to three calls in flight")
         res = {
