@@ -2874,6 +2874,7 @@ KERNEL_NAME(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans
 #ifndef LC3_BIG
 #include "lc3_enc_front4.inc"      /* lc3_enc_front4_kernel: the same for N = 480, four frames per wave */
 #include "lc3_enc_pitch2.inc"      /* lc3_enc_pitch2_kernel: the pitch chain, two streams per wave */
+#include "lc3_enc_frontm.inc"      /* lc3_enc_frontm_kernel: the front for the short prime-factor frame lengths, several frames per wave */
 #endif
 #include "lc3_enc_seq.inc"         /* lc3_enc_pitch_kernel: the pitch chain of the pipelined path */
 #include "lc3_enc_rate.inc"        /* lc3_enc_shape_kernel, lc3_enc_rate_kernel, lc3_enc_tail_kernel (or _big): the rate chain and its frame-parallel neighbours */
@@ -2915,7 +2916,7 @@ struct lc3hip_ctx {
     void* hp_dpcm[2]; void* hp_pin_in[2]; size_t hp_pcm_cap, hp_pin_in_cap;
     hipStream_t s_h2d; hipEvent_t ev_h2d[2], ev_k[2];
     hipStream_t s_pre, s_fr, s_pit, s_ln, s_rt; hipEvent_t ev_rate; hipEvent_t ev_fork, ev_p[LC3D_MAX_RUNS], ev_f[LC3D_MAX_RUNS], ev_h[LC3D_MAX_RUNS], ev_m[LC3D_MAX_RUNS];   /* side streams: pitch chain, frame-parallel front, frame-parallel tail */
-    int ylen, srow, la, len12; const float* last_frec; int last_frec_frames;      /* the records of the last pipelined call (lc3hip_last_records) */
+    int ylen, srow, la, len12, fm_frames; const float* last_frec; int last_frec_frames;      /* the records of the last pipelined call (lc3hip_last_records) */
     hipStream_t stream, last_stream; hipEvent_t ev0, ev1; float last_ms;
 };
 
@@ -2938,7 +2939,9 @@ extern "C" int lc3hip_create(void** out_ctx, const lc3d_plan* plan, int n_stream
     HIPCHK_OR(hipSetDevice(device), free(c));
     c->n_streams = n_streams; c->channels = plan->channels; c->ncs = n_streams * plan->channels; c->N = plan->N;
     c->big = LC3D_LAYOUT_BIG(plan->N, plan->la);
-    c->hr = plan->hrmode; c->ylen = plan->ylen; c->la = plan->la; c->len12 = plan->len12; c->srow = LC3D_SROW(plan->ylen);
+    c->hr = plan->hrmode; c->ylen = plan->ylen; c->la = plan->la; c->len12 = plan->len12;
+    c->fm_frames = (!c->big && plan->pfa_nst >= 2 && plan->pfa_rad[0] <= 8 && plan->pfa_rad[1] <= 8 && (plan->pfa_nst < 3 || plan->pfa_rad[2] <= 8) && plan->N <= 240) ? (plan->N > 120 ? 4 : 8) : 0;      /* lc3_enc_frontm_kernel */
+    c->srow = LC3D_SROW(plan->ylen);
     { const char* e = getenv("LC3PLUS_ENC_FUSED"); c->fused = e && e[0] == '1'; }     /* diagnostic: the bitstream writer inside lc3_encode_kernel */
     c->state_words = LC3D_STATE_WORDS(c->big ? LC3D_MEMCAP_BIG : LC3D_MEMCAP_STD);
     HIPCHK_OR(hipMalloc((void**)&c->d_plan, sizeof(lc3d_plan)), lc3hip_destroy(c));
@@ -3153,6 +3156,8 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
             if (f4 < 0) { const char* e = getenv("LC3PLUS_ENC_FRONT4"); f4 = !(e && e[0] == '0'); }     /* diagnostic: 0 = the one-frame-at-a-time kernel for N = 480 too */
             if (f4 && !c->big && !scf_wave && c->N == 480 && c->la == 180 && (c->ylen & 15) == 0)
                 DUPL('f') hipLaunchKernelGGL(lc3_enc_front4_kernel, dim3((unsigned)c->ncs * (unsigned)((nt + 3) / 4)), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames, tb, nt, c->ncs, dspec, c->srow, dT, dt0, dfrec, xn_w, xprev, xprev_stride);
+            else if (f4 && c->fm_frames && !scf_wave)
+                hipLaunchKernelGGL(lc3_enc_frontm_kernel, dim3((unsigned)c->ncs * (unsigned)((nt + c->fm_frames - 1) / c->fm_frames)), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames, tb, nt, c->fm_frames, c->ncs, dspec, c->srow, dT, dt0, dfrec, xn_w, xprev, xprev_stride);
             else if (c->big) hipLaunchKernelGGL(lc3_enc_front_kernel_big, dim3((unsigned)c->ncs * fruns), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames, tb, nt, fpw, c->ncs, dspec, c->srow, dT, dt0, dfrec, xn_w, xprev, xprev_stride, scf_wave);
             else DUPL('f') hipLaunchKernelGGL(lc3_enc_front_kernel, dim3((unsigned)c->ncs * fruns), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames, tb, nt, fpw, c->ncs, dspec, c->srow, dT, dt0, dfrec, xn_w, xprev, xprev_stride, scf_wave);
             HIPCHK(hipEventRecord(c->ev_m[k], c->s_fr));                 /* the MDCT memory hand-over and the spectrum rows of the run are written */
