@@ -74,5 +74,9 @@ if ents:
 print(open("profiles/%s_c1_pmc.txt" % tag).read()[:3000])
 PY
 for w in $WL; do cp $OUT/bench_$w.json profiles/${TAG}_bench_$w.json; done
+# the metric's line once more, now that the counters of these sources exist: it carries traffic and the issue-rate roofline
+if echo "$WL" | grep -qw c1; then
+  timeout -k 10 240 python bench.py --workload c1 --steps 20 --warmup 3 > $OUT/bench_c1_with_counters.json 2>> $OUT/bench_c1.err && cp $OUT/bench_c1_with_counters.json profiles/${TAG}_bench_c1.json
+fi
 mkdir -p $OUT/profiles && cp profiles/${TAG}_* $OUT/profiles/
 ls profiles
