@@ -2881,6 +2881,7 @@ KERNEL_NAME(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans
 #include "lc3_dec_kernels.inc"     /* lc3_dec_{plc,imdct,synth}_kernel, or the _big imdct / synth kernels in the large-layout object */
 #ifndef LC3_BIG                 /* the large-layout object holds only its kernels */
 #include "lc3_dec_parse.inc"
+#include "lc3_dec_imdct4.inc"      /* lc3_dec_imdct4_kernel: the decoder's IMDCT for N = 480, four frames per wave */
 extern "C" __global__ void lc3_encode_kernel_big(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans, float* __restrict__ state,
                                                  const void* __restrict__ pcm, int bitdepth, int T, uint8_t* __restrict__ out, int out_stride, int ncs,
                                                  lc3d_trace* __restrict__ trace, int* __restrict__ dump, int dstride, const float* __restrict__ y12,
@@ -3542,6 +3543,11 @@ extern "C" int lc3hip_dec_decode(void* ctx, const void* frames, int frames_on_de
         hipLaunchKernelGGL(lc3_dec_imdct_kernel_big, dim3(ncf), dim3(WAVE), 0, s, c->d_plan, c->d_state, c->d_rec, c->d_ws, n_frames, c->ncs, c->d_ov, dtr);
         hipLaunchKernelGGL(lc3_dec_synth_kernel_big, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, c->d_rec, c->d_ws, c->d_ov, n_frames, dpcm, bps, c->ncs, dst, dtr);
     } else {
+        static int i4 = -1;
+        if (i4 < 0) { const char* e = getenv("LC3PLUS_DEC_IMDCT4"); i4 = !(e && e[0] == '0'); }     /* diagnostic: 0 = the one-frame-at-a-time kernel for N = 480 too */
+        if (i4 && !dtr && c->N == 480)
+            hipLaunchKernelGGL(lc3_dec_imdct4_kernel, dim3((unsigned)((size_t)c->ncs * ((n_frames + 3) / 4))), dim3(WAVE), 0, s, c->d_plan, c->d_state, c->d_rec, c->d_ws, n_frames, c->ncs, c->d_ov);
+        else
         hipLaunchKernelGGL(lc3_dec_imdct_kernel, dim3(ncf), dim3(WAVE), 0, s, c->d_plan, c->d_state, c->d_rec, c->d_ws, n_frames, c->ncs, c->d_ov, dtr);
         hipLaunchKernelGGL(lc3_dec_synth_kernel, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, c->d_rec, c->d_ws, c->d_ov, n_frames, dpcm, bps, c->ncs, dst, dtr);
     }
