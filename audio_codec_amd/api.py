@@ -27,7 +27,7 @@ EXPORTS = [
     "lc3_free_decoder_structs",
     "lc3plus_dec_batch_create", "lc3plus_dec_batch_destroy", "lc3plus_dec_batch_output_samples", "lc3plus_dec_batch_delay",
     "lc3plus_dec_batch_num_bytes", "lc3plus_dec_batch_set_num_bytes", "lc3plus_dec_batch_decode",
-    "lc3plus_dec_batch_last_kernel_ms",
+    "lc3plus_dec_batch_last_kernel_ms", "lc3plus_dec_batch_set_input_ready",
 ]
 
 
@@ -88,6 +88,7 @@ def load_library():
         for f in ("lc3plus_dec_batch_destroy", "lc3plus_dec_batch_output_samples", "lc3plus_dec_batch_delay"):
             getattr(L, f).argtypes = [C.c_void_p]
         L.lc3plus_dec_batch_num_bytes.argtypes = [C.c_void_p, C.c_int]
+        L.lc3plus_dec_batch_set_input_ready.argtypes = [C.c_void_p, C.c_int]
         L.lc3plus_dec_batch_set_num_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int]
         _LIB = L
     return _LIB
@@ -314,6 +315,12 @@ class DecBatch:
         if rc:
             raise LC3Error(rc, "lc3plus_dec_batch_decode_traced")
         return pcm, status, traces
+
+    def set_input_ready(self, ready=True):
+        """lc3plus_dec_batch_set_input_ready: the frames of every following device-pointer call are complete on the device when the call is made."""
+        rc = self.lib.lc3plus_dec_batch_set_input_ready(self.h, 1 if ready else 0)
+        if rc:
+            raise LC3Error(rc, "lc3plus_dec_batch_set_input_ready")
 
     def decode_device(self, d_frames_ptr, in_stride, T, d_pcm_ptr, bps=16, hip_stream=None, sync=False):
         """Device-resident variant: raw device pointers, no bad-frame flags."""

@@ -772,6 +772,11 @@ LC3_Error lc3plus_dec_batch_decode_traced(lc3plus_dec_batch* b, const void* fram
 }
 int lc3plus_dec_trace_sizeof(void) { return (int)sizeof(lc3d_dec_trace); }
 float lc3plus_dec_batch_last_kernel_ms(lc3plus_dec_batch* b) { return b ? lc3hip_dec_last_ms(b->dev) : 0.0f; }
+LC3_Error lc3plus_dec_batch_set_input_ready(lc3plus_dec_batch* b, int ready)
+{
+    if (!b) return LC3_NULL_ERROR;
+    return lc3hip_dec_set_input_ready(b->dev, ready) ? LC3_ERROR : LC3_OK;
+}
 
 /* ---- single-stream drop-in API (R/lc3.h:318-406) ---- */
 struct LC3_Dec {

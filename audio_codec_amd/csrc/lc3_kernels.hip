@@ -3424,6 +3424,9 @@ struct lc3hip_dctx {
     lc3d_dec_trace* d_trace; size_t trace_cap; uint8_t* d_status; size_t status_cap;
     int* d_rec; float* d_ws; float* d_ov; size_t hand_cap; int max_nbytes; int* h_nbytes;
     hipStream_t stream, last_stream; hipEvent_t ev0, ev1; float last_ms;
+    /* lc3hip_dec_set_input_ready: the parse kernel of a call runs on a stream of its own beside the transform and synthesis of the call before; a
+     * second set of hand-over buffers (records, spectrum rows), alternating */
+    int input_ready, set; int* d_rec2; float* d_ws2; size_t hand2_cap; hipStream_t s_par; hipEvent_t ev_par[2], ev_free[2]; int free_armed[2];
 };
 extern "C" int lc3hip_dec_destroy(void* ctx);
 extern "C" int lc3hip_dec_create(void** out_ctx, const lc3d_plan* plan, int n_streams, int device)
@@ -3520,6 +3523,29 @@ extern "C" int lc3hip_dec_decode(void* ctx, const void* frames, int frames_on_de
             c->hand_cap = cf;
         }
     }
+    /* Under the input-ready promise (the frames of a call are complete on the device when the call is made) the parse kernel - stateless: a frame's
+     * record and spectrum row depend on that frame's bytes only - does not wait for what is queued on s: it runs on its own stream into the other set of
+     * hand-over buffers while the concealment bookkeeping, transform and synthesis of the call before (the stateful part, in order on s) read theirs. */
+    const bool ahead = c->input_ready && frames_on_device && pcm_on_device && !bfi_host && !trace_host && !status_host;
+    int* rec_w = c->d_rec; float* ws_w = c->d_ws;
+    if (ahead) {
+        const size_t cf = (size_t)c->ncs * n_frames;
+        if (!c->s_par) {
+            HIPCHK(hipStreamCreateWithFlags(&c->s_par, hipStreamNonBlocking));
+            for (int i = 0; i < 2; i++) { HIPCHK(hipEventCreateWithFlags(&c->ev_par[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_free[i], hipEventDisableTiming)); }
+        }
+        if (c->hand2_cap < cf) {
+            HIPCHK(hipDeviceSynchronize());
+            if (c->d_rec2) HIPCHK(hipFree(c->d_rec2));
+            if (c->d_ws2) HIPCHK(hipFree(c->d_ws2));
+            c->d_rec2 = nullptr; c->d_ws2 = nullptr; c->hand2_cap = 0;
+            HIPCHK(hipMalloc((void**)&c->d_rec2, cf * PR_WORDS * sizeof(int)));
+            HIPCHK(hipMalloc((void**)&c->d_ws2, cf * WS_ROW(c->N) * sizeof(float)));
+            c->hand2_cap = cf;
+        }
+        if (c->set) { rec_w = c->d_rec2; ws_w = c->d_ws2; }
+    }
+    hipStream_t sp = ahead ? c->s_par : s;
     /* frames of up to 128 bytes are staged in LDS; larger ones would cut the waves per workgroup and are read from global memory */
     const int nw_max = c->max_nbytes > 128 ? 0 : c->max_nbytes > 0 ? (c->max_nbytes + 3) / 4 : 1;
     const int nlw = (WS_ROW(c->N) / 2 + 31) / 32;                          /* >= (ylen / 2 + 31) / 32 of the plan */
@@ -3531,27 +3557,31 @@ extern "C" int lc3hip_dec_decode(void* ctx, const void* frames, int frames_on_de
     HIPCHK(hipEventRecord(c->ev0, s));
     /* parse: one stream-frame per lane; concealment bookkeeping: one channel-stream per lane; IMDCT: one channel-frame per wave;
      * synthesis: one channel-stream per wave (lc3_dec_kernels.inc) */
-    if (nw_max) hipLaunchKernelGGL(lc3_dec_parse_kernel, dim3((unsigned)((tasks + per_wg - 1) / per_wg)), dim3(wpg * WAVE), per_wave * wpg, s, c->d_plan, c->d_chans, din, in_stride,
-                                   dbfi, n_frames, c->n_streams, nw_max, c->d_rec, c->d_ws, WS_ROW(c->N));
-    else hipLaunchKernelGGL(lc3_dec_parse_kernel_g, dim3((unsigned)((tasks + per_wg - 1) / per_wg)), dim3(wpg * WAVE), per_wave * wpg, s, c->d_plan, c->d_chans, din, in_stride,
-                            dbfi, n_frames, c->n_streams, nw_max, c->d_rec, c->d_ws, WS_ROW(c->N));
+    if (ahead && c->free_armed[c->set]) HIPCHK(hipStreamWaitEvent(sp, c->ev_free[c->set], 0));      /* this set was last read by the synthesis of the call before the previous one */
+    if (nw_max) hipLaunchKernelGGL(lc3_dec_parse_kernel, dim3((unsigned)((tasks + per_wg - 1) / per_wg)), dim3(wpg * WAVE), per_wave * wpg, sp, c->d_plan, c->d_chans, din, in_stride,
+                                   dbfi, n_frames, c->n_streams, nw_max, rec_w, ws_w, WS_ROW(c->N));
+    else hipLaunchKernelGGL(lc3_dec_parse_kernel_g, dim3((unsigned)((tasks + per_wg - 1) / per_wg)), dim3(wpg * WAVE), per_wave * wpg, sp, c->d_plan, c->d_chans, din, in_stride,
+                            dbfi, n_frames, c->n_streams, nw_max, rec_w, ws_w, WS_ROW(c->N));
     HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(lc3_dec_plc_kernel, dim3((unsigned)((c->ncs + WAVE - 1) / WAVE)), dim3(WAVE), 0, s, c->d_plan, c->d_state, c->d_rec, n_frames, c->ncs);
+    if (ahead) { HIPCHK(hipEventRecord(c->ev_par[c->set], sp)); HIPCHK(hipStreamWaitEvent(s, c->ev_par[c->set], 0)); }
+    hipLaunchKernelGGL(lc3_dec_plc_kernel, dim3((unsigned)((c->ncs + WAVE - 1) / WAVE)), dim3(WAVE), 0, s, c->d_plan, c->d_state, rec_w, n_frames, c->ncs);
     HIPCHK(hipGetLastError());
     const unsigned ncf = (unsigned)((size_t)c->ncs * ((n_frames + IMDCT_FPW - 1) / IMDCT_FPW));     /* runs of IMDCT_FPW frames */
     if (c->big) {
-        hipLaunchKernelGGL(lc3_dec_imdct_kernel_big, dim3(ncf), dim3(WAVE), 0, s, c->d_plan, c->d_state, c->d_rec, c->d_ws, n_frames, c->ncs, c->d_ov, dtr);
-        hipLaunchKernelGGL(lc3_dec_synth_kernel_big, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, c->d_rec, c->d_ws, c->d_ov, n_frames, dpcm, bps, c->ncs, dst, dtr);
+        hipLaunchKernelGGL(lc3_dec_imdct_kernel_big, dim3(ncf), dim3(WAVE), 0, s, c->d_plan, c->d_state, rec_w, ws_w, n_frames, c->ncs, c->d_ov, dtr);
+        hipLaunchKernelGGL(lc3_dec_synth_kernel_big, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, rec_w, ws_w, c->d_ov, n_frames, dpcm, bps, c->ncs, dst, dtr);
     } else {
         static int i4 = -1;
         if (i4 < 0) { const char* e = getenv("LC3PLUS_DEC_IMDCT4"); i4 = !(e && e[0] == '0'); }     /* diagnostic: 0 = the one-frame-at-a-time kernel for N = 480 too */
         if (i4 && !dtr && c->N == 480)
-            hipLaunchKernelGGL(lc3_dec_imdct4_kernel, dim3((unsigned)((size_t)c->ncs * ((n_frames + 3) / 4))), dim3(WAVE), 0, s, c->d_plan, c->d_state, c->d_rec, c->d_ws, n_frames, c->ncs, c->d_ov);
+            hipLaunchKernelGGL(lc3_dec_imdct4_kernel, dim3((unsigned)((size_t)c->ncs * ((n_frames + 3) / 4))), dim3(WAVE), 0, s, c->d_plan, c->d_state, rec_w, ws_w, n_frames, c->ncs, c->d_ov);
         else
-        hipLaunchKernelGGL(lc3_dec_imdct_kernel, dim3(ncf), dim3(WAVE), 0, s, c->d_plan, c->d_state, c->d_rec, c->d_ws, n_frames, c->ncs, c->d_ov, dtr);
-        hipLaunchKernelGGL(lc3_dec_synth_kernel, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, c->d_rec, c->d_ws, c->d_ov, n_frames, dpcm, bps, c->ncs, dst, dtr);
+        hipLaunchKernelGGL(lc3_dec_imdct_kernel, dim3(ncf), dim3(WAVE), 0, s, c->d_plan, c->d_state, rec_w, ws_w, n_frames, c->ncs, c->d_ov, dtr);
+        hipLaunchKernelGGL(lc3_dec_synth_kernel, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, rec_w, ws_w, c->d_ov, n_frames, dpcm, bps, c->ncs, dst, dtr);
     }
     HIPCHK(hipGetLastError());
+    if (ahead) { HIPCHK(hipEventRecord(c->ev_free[c->set], s)); c->free_armed[c->set] = 1; c->set ^= 1; }
+    else if (c->s_par) { HIPCHK(hipEventRecord(c->ev_free[0], s)); c->free_armed[0] = 1; }      /* an ordered call reads the first set: a later parse-ahead into it waits for this one */
     c->last_stream = s;
     HIPCHK(hipEventRecord(c->ev1, s));
     if (!pcm_on_device) HIPCHK(hipMemcpyAsync(pcm, dpcm, pcm_bytes, hipMemcpyDeviceToHost, s));
@@ -3561,6 +3591,13 @@ extern "C" int lc3hip_dec_decode(void* ctx, const void* frames, int frames_on_de
         HIPCHK(hipStreamSynchronize(s));
         float ms = 0; if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->last_ms = ms;
     }
+    return 0;
+}
+extern "C" int lc3hip_dec_set_input_ready(void* ctx, int ready)
+{
+    lc3hip_dctx* c = (lc3hip_dctx*)ctx;
+    if (!c) return 1;
+    c->input_ready = ready != 0;
     return 0;
 }
 extern "C" size_t lc3hip_dec_state_bytes(void* ctx) { lc3hip_dctx* c = (lc3hip_dctx*)ctx; return c ? sizeof(float) * (size_t)DST_WORDS * (size_t)c->ncs : 0; }
@@ -3589,7 +3626,8 @@ extern "C" int lc3hip_dec_destroy(void* ctx)
     if (!c) return 0;
     hipSetDevice(c->device);
     hipDeviceSynchronize();
-    void* bufs[] = {c->d_plan, c->d_chans, c->d_state, c->d_in, c->d_pcm, c->d_bfi, c->d_trace, c->d_status, c->d_rec, c->d_ws, c->d_ov};
+    void* bufs[] = {c->d_plan, c->d_chans, c->d_state, c->d_in, c->d_pcm, c->d_bfi, c->d_trace, c->d_status, c->d_rec, c->d_ws, c->d_ov, c->d_rec2, c->d_ws2};
+    if (c->s_par) { hipStreamDestroy(c->s_par); for (int i = 0; i < 2; i++) { hipEventDestroy(c->ev_par[i]); hipEventDestroy(c->ev_free[i]); } }
     for (void* p : bufs) if (p) hipFree(p);
     if (c->stream) hipStreamDestroy(c->stream);
     if (c->ev0) hipEventDestroy(c->ev0);

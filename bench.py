@@ -277,6 +277,7 @@ def main():
         batch.encode_device(pcm.data_ptr(), 16, T, out.data_ptr(), stride, hip_stream=stream.cuda_stream, sync=True)
         dec = audio_codec_amd.DecBatch(B, fs, ch, ms, hr, nbl, device=local)
         back = torch.zeros(B, T, ch, n, dtype=torch.int16, device=dev)
+        dec.set_input_ready(not a.serial_calls)      # the frames are resident and complete before the timed region (include/lc3plus_batch.h)
         step = lambda: dec.decode_device(out.data_ptr(), stride, T, back.data_ptr(), 16, hip_stream=stream.cuda_stream)
     else:
         # the PCM is resident and complete before the timed region: say so, and consecutive calls overlap (include/lc3plus_batch.h)

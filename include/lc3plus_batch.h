@@ -101,6 +101,11 @@ float     lc3plus_dec_batch_last_kernel_ms(lc3plus_dec_batch* batch);
 size_t    lc3plus_dec_batch_state_size(const lc3plus_dec_batch* batch);
 LC3_Error lc3plus_dec_batch_get_state(lc3plus_dec_batch* batch, void* state, size_t size);
 LC3_Error lc3plus_dec_batch_set_state(lc3plus_dec_batch* batch, const void* state, size_t size);
+/* The decoder's counterpart of lc3plus_enc_batch_set_input_ready: with ready != 0 the caller guarantees that the frames passed to every
+ * following decode() call with device pointers (no bad-frame flags, no status) are COMPLETE in device memory when the call is made.  The
+ * bitstream parser of a call - stateless - then runs on a stream of the batch beside the transform and synthesis of the call before; results
+ * are identical, and the PCM of a call is complete in stream order on hip_stream as before.  Off by default. */
+LC3_Error lc3plus_dec_batch_set_input_ready(lc3plus_dec_batch* batch, int ready);
 
 /* lc3plus_enc_* spellings of the single-stream API (north-star wording); thin aliases. */
 LC3_Error lc3plus_enc_init(LC3_Enc* e, int samplerate, int channels);

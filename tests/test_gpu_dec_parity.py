@@ -329,3 +329,38 @@ def test_soak_every_operating_point():
     soak = importlib.util.module_from_spec(spec); spec.loader.exec_module(soak)
     tot, bad = soak.run(2, 12, 30, verbose=False)
     assert tot > 24 * 2 * 12 * 30 and bad == 0, (tot, bad)
+
+
+@pytest.mark.parametrize("fs,ms,hr,rates,B,T,K", [(48000, 10.0, 0, [64000, 128000, 32000], 192, 12, 5), (16000, 5.0, 0, [32000, 64000], 128, 20, 4)])
+def test_consecutive_device_calls_overlap_with_input_ready(fs, ms, hr, rates, B, T, K):
+    """lc3plus_dec_batch_set_input_ready: K device-pointer calls queued back to back without a host synchronisation in between - the parser of
+    call k+1 runs on its own stream beside the transform and synthesis of call k, into the other set of hand-over buffers - give the samples
+    of one continuous decode (the oracle decoder); then an ordered call (host pointers) and the promise withdrawn again."""
+    from test_gpu_parity import _Dev
+    amd = _amd()
+    d = _Dev()
+    try:
+        TT = T * K + 2 * T
+        br = [rates[i % len(rates)] for i in range(B)]
+        frames, nbytes, _ = make_dec_case(fs, ms, hr, 1, br, TT, seed=77 + B)
+        dec = amd.DecBatch(B, fs, 1, ms, hr, nbytes, device=0)
+        stride = frames.shape[2]; N = dec.N
+        dec.set_input_ready(True)
+        ins = [d.put(frames[:, k * T:(k + 1) * T]) for k in range(K)]
+        outs = [d.zeros(B * T * N * 2) for _ in range(K)]
+        d.sync()                                          # the promise: all frames are on the device before the first call
+        for k in range(K):
+            dec.decode_device(ins[k], stride, T, outs[k], 16, hip_stream=None, sync=False)
+        d.sync()
+        got = [d.get(outs[k], (B, T, 1, N), np.int16) for k in range(K)]
+        a, _ = dec.decode(frames[:, K * T:(K + 1) * T])                      # host pointers: the ordered path, first set of buffers
+        dec.set_input_ready(False)
+        pin = d.put(frames[:, (K + 1) * T:]); pout = d.zeros(B * T * N * 2)
+        dec.decode_device(pin, stride, T, pout, 16, hip_stream=None, sync=True)
+        got += [a, d.get(pout, (B, T, 1, N), np.int16)]
+        got = np.concatenate(got, axis=1)
+        want, _ = oracle_decode_streams(frames, nbytes, None, fs, ms, hr, 1)
+        bad = np.argwhere((got != want).any(axis=(2, 3)))
+        assert len(bad) == 0, ("first differing (stream, frame)", bad[:4].tolist())
+    finally:
+        d.free()
