@@ -55,7 +55,7 @@ LC3_Error lc3plus_enc_batch_set_state(lc3plus_batch* batch, const void* state, s
  * encode() call is COMPLETE in device memory when the call is made - not merely queued earlier on hip_stream (so it is wrong for PCM
  * that a kernel or copy queued on hip_stream is still producing).  The batch then lets the frame-parallel and pitch kernels of a
  * call start on its own streams while the sequential tail and the bitstream writer of the previous call on the same hip_stream are
- * still running (consecutive calls of equal n_frames, taken for calls of up to 40 frames, where it pays); results are identical, and the output of a call is complete in stream order
+ * still running (consecutive calls of equal n_frames of up to 256 frames; up to three calls are then in flight); results are identical, and the output of a call is complete in stream order
  * on hip_stream as before.  Streaming servers that fill their PCM ring ahead of the encode calls are the use. */
 LC3_Error lc3plus_enc_batch_set_input_ready(lc3plus_batch* batch, int ready);
 
