@@ -224,7 +224,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--streams", type=int, default=0, help="independent streams per GPU (default: the workload's; c1: 4096 = BASELINE configs[1])")
     ap.add_argument("--frames", type=int, default=0, help="frames per stream per step (default: the workload's; c1: 64, SURVEY 8(d))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
