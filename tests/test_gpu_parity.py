@@ -790,3 +790,36 @@ def test_odd_stream_counts_and_unaligned_pcm_on_the_pipelined_path(B, T, off):
         assert not bad, (len(bad), bad[:8])
     finally:
         d.free()
+
+
+@pytest.mark.parametrize("env", ["LC3PLUS_ENC_FRONT4=0", "LC3PLUS_ENC_PITCH2=0", "LC3PLUS_ENC_RATE_STREAM=1", "LC3PLUS_ENC_PACK_WPG=1", "LC3PLUS_DEC_IMDCT4=0"])
+def test_diagnostic_switches_give_the_same_bytes(env):
+    """The kernels the defaults replaced (one frame at a time front / IMDCT, one stream per wave pitch chain) and the stream / workgroup switches
+    still produce the oracle's bytes: a child process per switch (the library reads them once)."""
+    import subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import audio_codec_amd
+        from lc3_harness import synth_pcm, oracle_decode_streams
+        from test_gpu_parity import _oracle_batch
+        B, T, N, fs = 96, 22, 480, 48000
+        br = [[64000, 128000, 32000][i %% 3] for i in range(B)]
+        pcm = synth_pcm(B, T, N, fs, seed=99)
+        b = audio_codec_amd.Batch(B, fs, 1, 10.0, 0, br, device=0)
+        got = np.concatenate([b.encode(pcm[:, :9]), b.encode(pcm[:, 9:])], axis=1)
+        want = _oracle_batch(pcm, fs, 10.0, 0, br, b.stride)
+        nb = [b.num_bytes(i) for i in range(B)]
+        bad = [(i, t) for i in range(B) for t in range(T) if (got[i, t, :nb[i]] != want[i, t, :nb[i]]).any()]
+        assert not bad, bad[:6]
+        d = audio_codec_amd.DecBatch(B, fs, 1, 10.0, 0, nb, device=0)
+        out, _ = d.decode(got[:, :, :max(nb)].copy())
+        ref, _ = oracle_decode_streams(got[:, :, :max(nb)].copy(), nb, None, fs, 10.0, 0, 1)
+        assert (out == ref).all()
+        print("ok")
+    """ % (root, os.path.join(root, "tests")))
+    k, v = env.split("=")
+    e = dict(os.environ); e[k] = v
+    r = subprocess.run([sys.executable, "-c", code], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, (env, r.stdout[-300:], r.stderr[-800:])

@@ -1,0 +1,16 @@
+"""The resampler's lane assignment (lc3t_rs48_map in audio_codec_amd/csrc/lc3_enc_pre.inc, found by tools/rs48_map.py): a permutation of the 128 outputs,
+both outputs of a lane of one filter phase, every half-wave's 32 input indices in 32 different LDS banks."""
+import math, os, re
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_rs48_map_is_a_conflict_free_permutation():
+    src = open(os.path.join(ROOT, "audio_codec_amd", "csrc", "lc3_enc_pre.inc")).read()
+    m = re.search(r"lc3t_rs48_map\[128\] = \{([^}]*)\}", src)
+    v = [int(x) for x in m.group(1).replace("\n", " ").split(",")]
+    assert len(v) == 128 and sorted(v) == list(range(128))
+    n0, n1 = v[:64], v[64:]
+    assert all(a % 4 == b % 4 for a, b in zip(n0, n1))                       # same polyphase branch: 15 n mod 4
+    bank = lambda n: math.ceil(15 * n / 4) % 32                               # first input sample of output n (R/resamp12k8.c:48-57), LDS bank of a dword
+    for g in (n0[:32], n0[32:], n1[:32], n1[32:]):
+        assert len({bank(n) for n in g}) == 32
