@@ -2916,7 +2916,7 @@ struct lc3hip_ctx {
     /* host-pointer pipeline (lc3hip_encode_host): two chunk slots, each with device staging and (for pageable callers) pinned staging */
     void* hp_dpcm[2]; void* hp_pin_in[2]; size_t hp_pcm_cap, hp_pin_in_cap;
     hipStream_t s_h2d; hipEvent_t ev_h2d[2], ev_k[2];
-    hipStream_t s_pre, s_fr, s_pit, s_ln, s_rt; hipEvent_t ev_rate; hipEvent_t ev_fork, ev_p[LC3D_MAX_RUNS], ev_f[LC3D_MAX_RUNS], ev_h[LC3D_MAX_RUNS], ev_m[LC3D_MAX_RUNS];   /* side streams: pitch chain, frame-parallel front, frame-parallel tail */
+    hipStream_t s_pre, s_fr, s_pit, s_ln, s_rt; hipEvent_t ev_rate; int rate_armed, mean_nbytes; int* h_nb; hipEvent_t ev_fork, ev_p[LC3D_MAX_RUNS], ev_f[LC3D_MAX_RUNS], ev_h[LC3D_MAX_RUNS], ev_m[LC3D_MAX_RUNS];   /* side streams: pitch chain, frame-parallel front, frame-parallel tail */
     int ylen, srow, la, len12, fm_frames; const float* last_frec; int last_frec_frames;      /* the records of the last pipelined call (lc3hip_last_records) */
     hipStream_t stream, last_stream; hipEvent_t ev0, ev1; float last_ms;
 };
@@ -2984,6 +2984,10 @@ extern "C" int lc3hip_upload_chans(void* ctx, const lc3d_chan* chans, int first,
     for (int i = 0; i < count; i++) c->h_attack[first + i] = chans[i].attack_handling != 0 || chans[i].reset_attack != 0;   /* a pending reset needs the kernel too */
     c->any_attack = 0;
     for (int i = 0; i < c->ncs; i++) c->any_attack |= c->h_attack[i];
+    /* mean frame size: decides where the rate chain runs (enc_launch) */
+    if (!c->h_nb) { c->h_nb = (int*)calloc((size_t)c->ncs, sizeof(int)); if (!c->h_nb) return 1; }
+    for (int i = 0; i < count; i++) c->h_nb[first + i] = chans[i].nbytes;
+    { long long sum = 0; for (int i = 0; i < c->ncs; i++) sum += c->h_nb[i]; c->mean_nbytes = (int)(sum / (c->ncs > 0 ? c->ncs : 1)); }
     return 0;
 }
 
@@ -3073,12 +3077,7 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
             { const char* e = getenv("LC3PLUS_ENC_STREAMS"); c->s_pit = c->s_pre; c->s_ln = c->s_fr;
               if (e && atoi(e) >= 5) { HIPCHK(hipStreamCreateWithFlags(&c->s_pit, hipStreamNonBlocking)); HIPCHK(hipStreamCreateWithFlags(&c->s_ln, hipStreamNonBlocking)); } }
             for (int i = 0; i < LC3D_MAX_RUNS; i++) { HIPCHK(hipEventCreateWithFlags(&c->ev_h[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_m[i], hipEventDisableTiming)); }
-            /* LC3PLUS_ENC_RATE_STREAM=1 (diagnostic): the rate chain on a stream of its own, so that the rate kernel of call k+1 runs beside the bitstream
-             * writer of call k (which stays on the caller's stream: it is what the caller waits for).  Measured: calls of 16 frames (c3) +5 %, calls of 64
-             * frames (c1) 0 ... -11 % - a fourth side stream shares one of HIP's four hardware queues with another one, depending on what else the
-             * process created: off by default */
-            { const char* e = getenv("LC3PLUS_ENC_RATE_STREAM"); c->s_rt = NULL;
-              if (e && e[0] == '1') HIPCHK(hipStreamCreateWithFlags(&c->s_rt, hipStreamNonBlocking)); }
+            c->s_rt = NULL;
             HIPCHK(hipEventCreateWithFlags(&c->ev_rate, hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
             for (int i = 0; i < LC3D_SETS; i++) HIPCHK(hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming));
@@ -3110,12 +3109,22 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
         const float* xprev = ahead ? c->d_xnext[(c->xn_par + LC3D_SETS) % (LC3D_SETS + 1)] : c->d_state + LC3D_ST_XPREV;
         const int xprev_stride = ahead ? mc : c->state_words;
         const bool five = c->s_pit != c->s_pre;
+        /* The rate chain on a stream of its own, so that the rate kernel of call k+1 runs beside the bitstream writer of call k (which stays on the
+         * caller's stream: it is what the caller waits for).  It pays where the caller's stream - rate kernel + writer - is the longest of the three:
+         * large frames (the writer's work grows with the bytes: c96 22 -> 32 Mframes/s, c5 77 -> 83) and short calls (c3 +3 %); on 80-byte frames in
+         * calls of 64 (c1) a fourth side stream costs 0 ... 11 % (it shares one of HIP's four hardware queues with another, depending on what else the
+         * process created), and on c4 4 %.  LC3PLUS_ENC_RATE_STREAM=0 / 1 forces the choice (diagnostic). */
+        static int rt_env = -2;
+        if (rt_env == -2) { const char* e = getenv("LC3PLUS_ENC_RATE_STREAM"); rt_env = !e ? -1 : e[0] == '1' ? 1 : e[0] == '0' ? 0 : -1; }
+        const bool want_rt = rt_env == 1 || (rt_env < 0 && (c->mean_nbytes >= 120 || n_frames <= 32));
+        if (want_rt && !c->s_rt) HIPCHK(hipStreamCreateWithFlags(&c->s_rt, hipStreamNonBlocking));
+        hipStream_t rts = want_rt ? c->s_rt : NULL;          /* NULL: the rate kernels run on the caller's stream */
         if (!ahead) {
             HIPCHK(hipEventRecord(c->ev_fork, s)); HIPCHK(hipStreamWaitEvent(c->s_pre, c->ev_fork, 0)); HIPCHK(hipStreamWaitEvent(c->s_fr, c->ev_fork, 0));
             if (five) { HIPCHK(hipStreamWaitEvent(c->s_pit, c->ev_fork, 0)); HIPCHK(hipStreamWaitEvent(c->s_ln, c->ev_fork, 0)); }
-            if (c->s_rt) HIPCHK(hipStreamWaitEvent(c->s_rt, c->ev_fork, 0));
+            if (rts) HIPCHK(hipStreamWaitEvent(rts, c->ev_fork, 0));
         } else {
-            if (c->s_rt) HIPCHK(hipStreamWaitEvent(c->s_rt, c->ev_done[hb_], 0));       /* the records the rate kernel writes were last read by that writer */
+            if (rts) HIPCHK(hipStreamWaitEvent(rts, c->ev_done[hb_], 0));       /* the records the rate kernel writes were last read by that writer */
             HIPCHK(hipStreamWaitEvent(c->s_pre, c->ev_m[R - 1], 0));    /* the resampler reads the hand-over the previous call's last front kernel wrote */
             HIPCHK(hipStreamWaitEvent(c->s_pre, c->ev_done[hb_], 0)); HIPCHK(hipStreamWaitEvent(c->s_fr, c->ev_done[hb_], 0));
             if (five) { HIPCHK(hipStreamWaitEvent(c->s_pit, c->ev_done[hb_], 0)); HIPCHK(hipStreamWaitEvent(c->s_ln, c->ev_done[hb_], 0));
@@ -3127,6 +3136,7 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
          * streams than these two do not help: HIP multiplexes streams onto a few hardware queues and kernels of two streams that share
          * one run back to back.) */
         hipStream_t rs = s;                                  /* where the rate kernels run */
+        if (c->rate_armed) { HIPCHK(hipStreamWaitEvent(rts ? rts : s, c->ev_rate, 0)); }      /* the rate chain is a chain: behind the previous call's, whichever stream that ran on */
         for (int k = 0, tb = 0, hb = 0, hk = 0; tb < n_frames; k++, tb += Tr) {
             const int nt = n_frames - tb < Tr ? n_frames - tb : Tr;
             if (tb >= hb) {
@@ -3176,7 +3186,7 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
                 const int spw = nt < sfpw ? nt : sfpw;
                 const unsigned sruns = (unsigned)((nt + spw - 1) / spw);
                 hipStream_t ss = son ? s : c->s_ln;
-                rs = (son || !c->s_rt) ? s : c->s_rt;
+                rs = (son || !rts) ? s : rts;
                 if (son) { HIPCHK(hipEventRecord(c->ev_f[k], c->s_ln)); HIPCHK(hipStreamWaitEvent(s, c->ev_f[k], 0)); }
                 static int swave = -1;
                 if (swave < 0) { const char* e = getenv("LC3PLUS_ENC_SHAPE_WAVE"); swave = e && e[0] == '1'; }     /* diagnostic: the wave-per-frame kernel */
@@ -3192,7 +3202,8 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
             else DUPL('s') hipLaunchKernelGGL(lc3_enc_rate_kernel, dim3((unsigned)((c->ncs + RATE_WG - 1) / RATE_WG)), dim3(RATE_WG * WAVE), 0, rs, c->d_plan, c->d_chans, c->d_state, dT, dt0 + tb, nt, c->ncs, dspec, c->srow, dfrec, xn_w, last);
             HIPCHK(hipGetLastError());
         }
-        if (rs != s) { HIPCHK(hipEventRecord(c->ev_rate, rs)); HIPCHK(hipStreamWaitEvent(s, c->ev_rate, 0)); }      /* the writer (and whatever the caller queues next) behind the rate chain */
+        HIPCHK(hipEventRecord(c->ev_rate, rs)); c->rate_armed = 1;
+        if (rs != s) HIPCHK(hipStreamWaitEvent(s, c->ev_rate, 0));      /* the writer (and whatever the caller queues next) behind the rate chain */
         c->ahead_ok = (dt0 == 0 && dT == n_frames && pack) ? 1 : 0; c->ahead_T = n_frames; c->ahead_R = R;
         c->xn_par = (c->xn_par + 1) % (LC3D_SETS + 1);
     }
@@ -3394,7 +3405,7 @@ extern "C" int lc3hip_destroy(void* ctx)
     if (c->d_status) hipFree(c->d_status);
     for (int i = 0; i < LC3D_SETS; i++) { if (c->d_spec[i]) hipFree(c->d_spec[i]); if (c->d_frec[i]) hipFree(c->d_frec[i]); }
     for (int i = 0; i < LC3D_SETS + 1; i++) if (c->d_xnext[i]) hipFree(c->d_xnext[i]);
-    free(c->h_attack);
+    free(c->h_attack); free(c->h_nb);
     for (int i = 0; i < 2; i++) {
         if (c->hp_dpcm[i]) hipFree(c->hp_dpcm[i]);
         if (c->hp_pin_in[i]) hipHostFree(c->hp_pin_in[i]);
