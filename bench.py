@@ -202,7 +202,7 @@ def committed_profile(workload, B, T):
     return {}
 
 
-def quick_workload(torch, amd, name, dev, local, steps=3, warmup=1):
+def quick_workload(torch, amd, name, dev, local, steps=10, warmup=4):
     """Another BASELINE configuration on this GPU, a few steps (the default line's `other_workloads`; the full lines: --workload NAME)."""
     fs, ms, hr, ch, n, rates, T, B, what = WORKLOADS[name]
     pcm = synth_pcm_device(torch, B, T, ch, n, fs, dev, seed=4321)
@@ -410,7 +410,7 @@ def main():
             res["t1"] = {"value": round(B * 200 / w1 / 1e6, 4), "unit": "Mframes/s", "ms_per_step": round(w1 / 200 * 1e3, 4),
                          "note": "%d streams x 1 frame per call (launch-latency regime: the kernels of a call run back to back on one stream)" % B}
         if a.workload == "c1" and not a.no_extras and world == 1:
-            # the other BASELINE configurations, three steps each (their own lines with rooflines: --workload c3 / c4 / c5 / c96)
+            # the other BASELINE configurations, ten steps each (their own lines with rooflines: --workload c3 / c4 / c5 / c96)
             res["other_workloads"] = {}
             for wn in ("c3", "c4", "c5", "c96"):
                 try:
