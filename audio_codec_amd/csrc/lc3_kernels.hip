@@ -2905,7 +2905,7 @@ extern "C" __global__ void lc3_enc_rate_kernel_big(const lc3d_plan* __restrict__
 #define LC3D_RUN_FRAMES 16            /* frames per run when consecutive calls do not overlap (measured, 4096 streams x 64 frames: 8: 58.1, 16: 64.9, 32: 62.8, 64: 58.6 Mframes/s) */
 #define LC3D_RUN_FRAMES_READY 64      /* under the input-ready promise (calls overlap, a call's own pipeline matters less: 8: 62.4, 16: 70.1, 32: 72.6, 64: 73.0) */
 struct lc3hip_ctx {
-    int device, ncs, n_streams, channels, N, big, state_words;
+    int device, ncs, n_streams, channels, N, big, state_words, rs48;
     lc3d_plan* d_plan; lc3d_chan* d_chans; float* d_state;
     void* d_pcm; size_t pcm_cap; uint8_t* d_out; size_t out_cap;
     lc3d_trace* d_trace; size_t trace_cap;
@@ -2943,6 +2943,8 @@ extern "C" int lc3hip_create(void** out_ctx, const lc3d_plan* plan, int n_stream
     c->hr = plan->hrmode; c->ylen = plan->ylen; c->la = plan->la; c->len12 = plan->len12;
     c->fm_frames = (!c->big && plan->pfa_nst >= 2 && plan->pfa_rad[0] <= 8 && plan->pfa_rad[1] <= 8 && (plan->pfa_nst < 3 || plan->pfa_rad[2] <= 8) && plan->N <= 240) ? (plan->N > 120 ? 4 : 8) : 0;      /* lc3_enc_frontm_kernel */
     c->srow = LC3D_SROW(plan->ylen);
+    c->rs48 = plan->N == 480 && plan->rs_stride == 4 && plan->n12 == 128 && plan->rs_mem_in_len == 60;      /* lc3_enc_resample48_kernel */
+    { const char* e = getenv("LC3PLUS_ENC_RESAMPLE48"); if (e && e[0] == '0') c->rs48 = 0; }     /* diagnostic: the two-outputs-per-lane kernel */
     { const char* e = getenv("LC3PLUS_ENC_FUSED"); c->fused = e && e[0] == '1'; }     /* diagnostic: the bitstream writer inside lc3_encode_kernel */
     c->state_words = LC3D_STATE_WORDS(c->big ? LC3D_MEMCAP_BIG : LC3D_MEMCAP_STD);
     HIPCHK_OR(hipMalloc((void**)&c->d_plan, sizeof(lc3d_plan)), lc3hip_destroy(c));
@@ -3003,6 +3005,15 @@ static int dup_of(char k) { static const char* e = nullptr; static bool rd = fal
 #else
 #define DUPL(k)
 #endif
+/* the 12.8 kHz polyphase FIR of frames hb ... hb + hn - 1 of every channel-stream on stream st: four outputs per lane where the shape allows */
+static void launch_resample(lc3hip_ctx* c, hipStream_t st, const void* dpcm, int bitdepth, int n_frames, int hb, int hn, int mc, float* dy12, const float* xprev, int xprev_stride)
+{
+    const unsigned pruns = (unsigned)((hn + PRE_FPW - 1) / PRE_FPW);
+    if (c->rs48 && bitdepth == 16 && (((size_t)dpcm) & 15) == 0)
+        hipLaunchKernelGGL(lc3_enc_resample48_kernel, dim3((unsigned)c->ncs * pruns), dim3(WAVE), 0, st, c->d_plan, (const int16_t*)dpcm, c->channels, mc, n_frames, hb, hn, c->ncs, dy12, xprev, xprev_stride);
+    else
+        hipLaunchKernelGGL(lc3_enc_resample_kernel, dim3((unsigned)c->ncs * pruns), dim3(WAVE), 0, st, c->d_plan, c->d_state, c->state_words, mc, dpcm, bitdepth, n_frames, hb, hn, c->ncs, dy12, xprev, xprev_stride);
+}
 static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frames, uint8_t* dout, int out_stride, hipStream_t s, lc3d_trace* dtr,
                       int dT, int dt0, bool pack)
 {
@@ -3046,8 +3057,7 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
         c->ahead_ok = 0; c->last_frec = nullptr; c->last_frec_frames = 0;
         /* everything in lc3_encode_kernel (traced, diagnostic and very short launches), behind the 12.8 kHz pre-kernels when they apply */
         if (dy12) {
-            const unsigned runs = (unsigned)((n_frames + PRE_FPW - 1) / PRE_FPW);
-            hipLaunchKernelGGL(lc3_enc_resample_kernel, dim3((unsigned)c->ncs * runs), dim3(WAVE), 0, s, c->d_plan, c->d_state, c->state_words, mc, dpcm, bitdepth, n_frames, 0, n_frames, c->ncs, dy12, c->d_state + LC3D_ST_XPREV, c->state_words);
+            launch_resample(c, s, dpcm, bitdepth, n_frames, 0, n_frames, mc, dy12, c->d_state + LC3D_ST_XPREV, c->state_words);
             hipLaunchKernelGGL(lc3_enc_hp50_kernel, dim3((unsigned)((c->ncs + WAVE - 1) / WAVE)), dim3(WAVE), 0, s, c->d_plan, c->d_state, c->state_words, LC3D_ST_SCAL(mc), n_frames, 0, n_frames, c->ncs, dy12);
             HIPCHK(hipGetLastError());
         }
@@ -3143,8 +3153,7 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
                 static int prn = 0;
                 if (!prn) { const char* e = getenv("LC3PLUS_ENC_PRE_RUNS"); prn = e && atoi(e) >= 1 ? atoi(e) : 3; }     /* diagnostic */
                 const int hn0 = hk == 0 ? Tr : prn * Tr, hn = n_frames - hb < hn0 ? n_frames - hb : hn0;
-                const unsigned pruns = (unsigned)((hn + PRE_FPW - 1) / PRE_FPW);
-                DUPL('r') hipLaunchKernelGGL(lc3_enc_resample_kernel, dim3((unsigned)c->ncs * pruns), dim3(WAVE), 0, c->s_pre, c->d_plan, c->d_state, c->state_words, mc, dpcm, bitdepth, n_frames, hb, hn, c->ncs, dy12, xprev, xprev_stride);
+                DUPL('r') launch_resample(c, c->s_pre, dpcm, bitdepth, n_frames, hb, hn, mc, dy12, xprev, xprev_stride);
                 DUPL('h') hipLaunchKernelGGL(lc3_enc_hp50_kernel, dim3((unsigned)((c->ncs + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->s_pre, c->d_plan, c->d_state, c->state_words, LC3D_ST_SCAL(mc), n_frames, hb, hn, c->ncs, dy12);
                 HIPCHK(hipGetLastError());
                 hb += hn; hk++;
@@ -3608,6 +3617,9 @@ extern "C" int lc3hip_dec_set_input_ready(void* ctx, int ready)
 {
     lc3hip_dctx* c = (lc3hip_dctx*)ctx;
     if (!c) return 1;
+    /* 0 -> 1: an ordered call made before the promise may still be reading the first set of hand-over buffers, and it recorded no event a parse-ahead
+     * could wait for (the side stream and its events exist from the first ahead call on): drain it once, as the encoder side does by clearing ahead_ok */
+    if (ready && !c->input_ready && c->last_stream) { HIPCHK(hipSetDevice(c->device)); HIPCHK(hipStreamSynchronize(c->last_stream)); }
     c->input_ready = ready != 0;
     return 0;
 }

@@ -40,7 +40,7 @@ WORKLOADS = {
     "d5": (48000, 10.0, 0, 1, 480, RATES12, 64, 4096, "decoder: the c5 bitstreams back to 16-bit PCM"),
 }
 HBM_PEAK_GBS = 8000.0                          # MI355X_MICROARCH.md: 8.0 TB/s spec
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
 
 
 # ----------------------------------------------------------------------------------------------------------------

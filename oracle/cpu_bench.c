@@ -12,6 +12,8 @@
  *   enc: IN_FILE = int16 [stream][frame][channel][N];  BITRATE = per stream, all channels together
  *   dec: IN_FILE = uint8 [stream][frame][NBYTES]
  *   OUT_FILE (optional): the encoded frames [stream][frame][nbytes] / decoded PCM, for a cross-check against the GPU output
+ * environment (enc only, tools/ref_soak.py): LC3_BENCH_BW_PLAN = file of int32 [stream][frame]; before frame t of stream s the bandwidth is set to
+ *   plan[s][t] when that is not 0 - the switching file of R/codec_exe.c:338-352 as an array (a refused value is ignored, as there)
  * prints one line: "frames seconds threads"
  */
 #define _POSIX_C_SOURCE 200809L
@@ -33,6 +35,7 @@
 #define ENC_SET_HR(h, v) lc3o_enc_set_hrmode((lc3o_enc*)(h), v)
 #define DEC_SET_HR(h, v) lc3o_dec_set_hrmode((lc3o_dec*)(h), v)
 #define ENC_SET_BR(h, v) lc3o_enc_set_bitrate((lc3o_enc*)(h), v)
+#define ENC_SET_BW(h, v) lc3o_enc_set_bandwidth((lc3o_enc*)(h), v)
 #define ENC_NB(h) lc3o_enc_get_num_bytes((lc3o_enc*)(h))
 #define ENC_N(h) lc3o_enc_get_input_samples((lc3o_enc*)(h))
 #define DEC_N(h) lc3o_dec_get_output_samples((lc3o_dec*)(h))
@@ -47,6 +50,7 @@ int lc3_enc_init(void* e, int samplerate, int channels);
 int lc3_enc_set_frame_ms(void* e, float ms);
 int lc3_enc_set_hrmode(void* e, int hr);
 int lc3_enc_set_bitrate(void* e, int br);
+int lc3_enc_set_bandwidth(void* e, int bw);
 int lc3_enc_get_num_bytes(const void* e);
 int lc3_enc_get_input_samples(const void* e);
 int lc3_enc_fl(void* e, void** in, int bitdepth, void* out, int* nb);
@@ -67,6 +71,7 @@ int lc3_free_decoder_structs(void* d);
 #define ENC_SET_HR(h, v) lc3_enc_set_hrmode(h, v)
 #define DEC_SET_HR(h, v) lc3_dec_set_hrmode(h, v)
 #define ENC_SET_BR(h, v) lc3_enc_set_bitrate(h, v)
+#define ENC_SET_BW(h, v) lc3_enc_set_bandwidth(h, v)
 #define ENC_NB(h) lc3_enc_get_num_bytes(h)
 #define ENC_N(h) lc3_enc_get_input_samples(h)
 #define DEC_N(h) lc3_dec_get_output_samples(h)
@@ -80,6 +85,7 @@ static struct {
     int dec, fs, hr, ch, rate, S, T;
     float ms;
     const uint8_t* in; uint8_t* out; size_t out_unit;
+    const int32_t* bw_plan;
 } G;
 
 typedef struct { int first, last, rc; long long sink; } job_t;
@@ -100,6 +106,7 @@ static void* work(void* arg)
         const int N = G.dec ? DEC_N(h) : ENC_N(h);
         for (int t = 0; t < G.T; t++) {
             if (!G.dec) {
+                if (G.bw_plan && G.bw_plan[(size_t)s * G.T + t]) (void)ENC_SET_BW(h, G.bw_plan[(size_t)s * G.T + t]);
                 const int16_t* p = (const int16_t*)G.in + ((size_t)s * G.T + t) * G.ch * N;
                 void* in[2] = {(void*)p, (void*)(p + N)};
                 int nb = ENC_NB(h);
@@ -153,6 +160,14 @@ int main(int argc, char** argv)
             out_len = (size_t)G.S * G.T * G.out_unit;
         } else out_len = (size_t)G.S * G.T * G.ch * Nio * 2;
         G.out = (uint8_t*)calloc(1, out_len);
+    }
+    if (!G.dec && getenv("LC3_BENCH_BW_PLAN")) {
+        FILE* bf = fopen(getenv("LC3_BENCH_BW_PLAN"), "rb");
+        const size_t nw = (size_t)G.S * G.T;
+        int32_t* plan = (int32_t*)malloc(nw * sizeof(int32_t));
+        if (!bf || !plan || fread(plan, sizeof(int32_t), nw, bf) != nw) { fprintf(stderr, "cpu_bench: cannot read the bandwidth plan\n"); return 2; }
+        fclose(bf);
+        G.bw_plan = plan;
     }
     pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)P);
     job_t* jobs = (job_t*)calloc((size_t)P, sizeof(job_t));

@@ -1336,6 +1336,30 @@ int lc3o_encode_batch16_ch(int samplerate, float frame_ms, int hrmode, int chann
     free(e);
     return rc;
 }
+/* the same for mono streams with a bandwidth plan [B][T]: before frame t of stream b the bandwidth is set to plan[b*T + t] when that is not 0
+ * (the switching file of R/codec_exe.c:338-352 as an array; a value the API refuses - R/lc3.c:197 - is ignored like there) */
+int lc3o_encode_batch16_bw(int samplerate, float frame_ms, int hrmode, int B, int T, const int* bitrate, const int* bw_plan,
+                           const int16_t* pcm, uint8_t* out, int stride)
+{
+    lc3o_enc* e = (lc3o_enc*)malloc(sizeof *e);
+    int rc = e ? LC3O_OK : LC3O_ERROR;
+    for (int b = 0; b < B && rc == LC3O_OK; b++) {
+        rc = lc3o_enc_init(e, samplerate, 1);
+        if (!rc) rc = lc3o_enc_set_frame_ms(e, frame_ms);
+        if (!rc) rc = lc3o_enc_set_hrmode(e, hrmode);
+        if (!rc) rc = lc3o_enc_set_bitrate(e, bitrate[b]);
+        if (rc) break;
+        const int N = e->N;
+        for (int t = 0; t < T && !rc; t++) {
+            if (bw_plan && bw_plan[(size_t)b * T + t]) (void)lc3o_enc_set_bandwidth(e, bw_plan[(size_t)b * T + t]);
+            void* in[1] = {(void*)(pcm + ((size_t)b * T + t) * N)};
+            int nb = 0;
+            rc = lc3o_enc_frame(e, in, 16, out + ((size_t)b * T + t) * stride, &nb);
+        }
+    }
+    free(e);
+    return rc;
+}
 int lc3o_encode_batch16(int samplerate, float frame_ms, int hrmode, int B, int T, const int* bitrate,
                         const int16_t* pcm, uint8_t* out, int stride)
 {

@@ -92,6 +92,8 @@ int  lc3o_dec_frame(lc3o_dec* d, const uint8_t* input, int num_bytes, void** out
 int  lc3o_dft(float* x, int n);      /* test hook: forward complex DFT of length n in place (interleaved re, im); 0 = no kernel */
 int  lc3o_encode_batch16_ch(int samplerate, float frame_ms, int hrmode, int channels, int B, int T, const int* bitrate,
                             const int16_t* pcm, uint8_t* out, int stride);
+int  lc3o_encode_batch16_bw(int samplerate, float frame_ms, int hrmode, int B, int T, const int* bitrate, const int* bw_plan /* [B][T], 0 = keep; may be NULL */,
+                            const int16_t* pcm, uint8_t* out, int stride);
 int  lc3o_encode_batch16(int samplerate, float frame_ms, int hrmode, int B, int T, const int* bitrate,
                          const int16_t* pcm, uint8_t* out, int stride);
 

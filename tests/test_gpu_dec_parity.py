@@ -364,3 +364,35 @@ def test_consecutive_device_calls_overlap_with_input_ready(fs, ms, hr, rates, B,
         assert len(bad) == 0, ("first differing (stream, frame)", bad[:4].tolist())
     finally:
         d.free()
+
+
+def test_promise_given_while_an_ordered_call_is_in_flight():
+    """an ASYNCHRONOUS ordered device-pointer call (promise off, sync = 0), then lc3plus_dec_batch_set_input_ready(1), then another
+    asynchronous call - the first 'ahead' call, whose parser must not overwrite the hand-over buffers the call before is still reading
+    (lc3hip_dec_set_input_ready drains the last stream on the 0 -> 1 transition).  Large enough that the first call is still running when the second
+    is queued; twice, so that the second set of buffers has been both."""
+    from test_gpu_parity import _Dev
+    amd = _amd()
+    d = _Dev()
+    try:
+        B, T, K = 2048, 24, 4
+        U = 128                                             # distinct streams, tiled: the oracle decodes 128
+        fr_u, nb_u, _ = make_dec_case(48000, 10.0, 0, 1, [64000, 96000] * (U // 2), T * K, seed=1234)
+        reps = B // U
+        frames = np.ascontiguousarray(np.tile(fr_u, (reps, 1, 1))); nbytes = list(nb_u) * reps
+        dec = amd.DecBatch(B, 48000, 1, 10.0, 0, nbytes, device=0)
+        stride = frames.shape[2]; N = dec.N
+        ins = [d.put(frames[:, k * T:(k + 1) * T]) for k in range(K)]
+        outs = [d.zeros(B * T * N * 2) for _ in range(K)]
+        d.sync()
+        for k in range(K):
+            dec.set_input_ready(k % 2 == 1)                # off, on, off, on: every 'on' call follows an ordered call that was not waited for
+            dec.decode_device(ins[k], stride, T, outs[k], 16, hip_stream=None, sync=False)
+        d.sync()
+        got = np.concatenate([d.get(outs[k], (B, T, 1, N), np.int16) for k in range(K)], axis=1)
+        want, _ = oracle_decode_streams(fr_u, nb_u, None, 48000, 10.0, 0, 1)
+        for r in range(reps):
+            bad = np.argwhere((got[r * U:(r + 1) * U] != want).any(axis=(2, 3)))
+            assert len(bad) == 0, ("copy", r, "first differing (stream, frame)", bad[:4].tolist())
+    finally:
+        d.free()

@@ -239,6 +239,46 @@ def test_cli_switching_files(tmp_path):
         assert ref == got
 
 
+def test_cli_encoder_g192_format_and_cfg_file(tmp_path):
+    """tools/lc3plus_enc_cli -formatG192 [-cfgG192 FILE] (R/codec_exe.c:705-749 write_bitstream_frame_G192: sync word 0x6B21, the frame's length in bits,
+    one int16 per bit - 0x0081 for 1, 0x007F for 0 - and the 20-byte header in a side file) against the ETSI CLI where it travelled (whole files, byte for
+    byte) and against the oracle's frames re-packed here; then both G.192 files back through the two decoders (tools/lc3plus_dec_cli vs LC3plus -D)."""
+    import subprocess
+    from lc3_harness import ORACLE_DIR
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cli = os.path.join(root, "tools", "lc3plus_enc_cli"); dcli = os.path.join(root, "tools", "lc3plus_dec_cli")
+    subprocess.check_call(["make", "-s", "-C", root, "cli"])
+    nfr, nsamp = 21, 480 * 20 + 77
+    pcm = synth_pcm(2, nfr, 480, 48000, seed=192).reshape(2, -1)[:, :nsamp]
+    wav = tmp_path / "in.wav"
+    _write_wav(wav, pcm.T.reshape(-1), 48000, 2, 16)
+    for cfg_opt in (False, True):
+        ours = tmp_path / ("ours%d.g192" % cfg_opt); cfg = tmp_path / ("ours%d.side" % cfg_opt)
+        args = [cli, "-E", "-q", "-formatG192"] + (["-cfgG192", str(cfg)] if cfg_opt else []) + [str(wav), str(ours), "128000"]
+        subprocess.check_call(args)
+        cfg_path = cfg if cfg_opt else str(ours) + ".cfg"
+        got, got_cfg = open(ours, "rb").read(), open(cfg_path, "rb").read()
+        o = Oracle(48000, 2, 10.0, 0, 128000, portable_math=True)
+        padded = np.zeros((2, nfr * 480), np.int16); padded[:, :nsamp] = pcm
+        want = bytearray()
+        for t in range(nfr):
+            fr = o.encode(padded[:, t * 480:(t + 1) * 480])
+            bits = np.unpackbits(fr, bitorder="little")
+            want += np.array([0x6B21, fr.size * 8], "<u2").tobytes() + np.where(bits, 0x0081, 0x007F).astype("<u2").tobytes()
+        assert got == bytes(want)
+        assert got_cfg == _container([], 48000, 128000, 2, 10.0, nsamp, 0)[:20]
+        ref_cli = os.path.join(ORACLE_DIR, "_ref", "LC3plus")
+        if os.path.exists(ref_cli):
+            theirs = tmp_path / ("ref%d.g192" % cfg_opt); tcfg = tmp_path / ("ref%d.side" % cfg_opt)
+            subprocess.check_call([ref_cli, "-E", "-q", "-formatG192"] + (["-cfgG192", str(tcfg)] if cfg_opt else []) + [str(wav), str(theirs), "128000"], stdout=subprocess.DEVNULL)
+            assert open(theirs, "rb").read() == got
+            assert open(tcfg if cfg_opt else str(theirs) + ".cfg", "rb").read() == got_cfg
+            a, b = tmp_path / "a.wav", tmp_path / "b.wav"
+            subprocess.check_call([dcli, "-D", "-q", "-formatG192"] + (["-cfgG192", str(cfg)] if cfg_opt else []) + [str(ours), str(a)])
+            subprocess.check_call([ref_cli, "-D", "-q", "-formatG192"] + (["-cfgG192", str(tcfg)] if cfg_opt else []) + [str(theirs), str(b)], stdout=subprocess.DEVNULL)
+            assert open(a, "rb").read() == open(b, "rb").read()
+
+
 def _oracle_batch(pcm, fs, ms, hr, rates, stride):
     """All streams through the oracle's C batch entry (same math as the device), [B, T, stride] uint8."""
     import ctypes as C
@@ -823,3 +863,63 @@ def test_diagnostic_switches_give_the_same_bytes(env):
     e = dict(os.environ); e[k] = v
     r = subprocess.run([sys.executable, "-c", code], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == 0 and "ok" in r.stdout, (env, r.stdout[-300:], r.stderr[-800:])
+
+
+@pytest.mark.parametrize("fs,ms,N,bws,ready", [
+    (48000, 10.0, 480, [0, 4000, 8000, 16000, 12000, 20000], False),
+    (48000, 10.0, 480, [0, 4000, 8000, 16000, 12000, 20000], True),
+    (32000, 5.0, 160, [0, 4000, 8000, 16000, 12000], False),
+    (32000, 5.0, 160, [0, 4000, 8000, 16000, 12000], True),
+    (24000, 10.0, 240, [0, 4000, 8000, 12000], True),
+])
+def test_bandwidth_controller_on_the_pipelined_path(fs, ms, N, bws, ready):
+    """lc3plus_enc_batch_set_bandwidth on the PRODUCT path: calls of 14 frames take the pipelined kernels, so the bandwidth
+    controller of lc3_enc_shape_lane_kernel (R/enc_lc3_fl.c:92-96, R/cutoff_bandwidth.c:13-26: fade 0.5 / 0.25 / 0.125 / 0.0625, then zeros) and the
+    limit on the detected bandwidth (R/enc_lc3_fl.c:68 -> R/detect_cutoff_warped.c) run one frame per lane.  Bandwidths mixed per stream (0 = none set)
+    inside one wave, a bandwidth switch between two calls - queued back to back under the input-ready promise when `ready` - against the oracle
+    with the same switches, and the records' bandwidth word (FR_BWC) against the oracle's trace.  The conformance procedure's band_limiting and
+    bandwidth_switching cases: E/conformance/lc3_conformance.py:835-862."""
+    amd = _amd()
+    d = _Dev()
+    try:
+        B, T, K = 150, 14, 4
+        rates = [64000, 32000, 96000, 128000]
+        br = [rates[i % len(rates)] for i in range(B)]
+        bw0 = [bws[i % len(bws)] for i in range(B)]
+        bw1 = [bws[(i // 7 + 1) % len(bws)] if i % 3 == 0 else bw0[i] for i in range(B)]          # a third of the streams switch after call 1
+        pcm = synth_pcm(B, T * K, N, fs, seed=808 + N)
+        b = amd.Batch(B, fs, 1, ms, 0, br, device=0)
+        stride = b.stride
+        for i in range(B):
+            if bw0[i]: assert b.set_bandwidth(i, bw0[i]) == 0, (i, bw0[i])
+        assert b.set_bandwidth(0, fs) == 18                                                         # LC3_BW_WARNING (R/lc3.c:197): above the limit, nothing changes
+        b.set_input_ready(ready)
+        ins = [d.put(pcm[:, k * T:(k + 1) * T]) for k in range(K)]
+        outs = [d.zeros(B * T * stride) for _ in range(K)]
+        d.sync()
+        recs = []
+        for k in range(K):
+            if k == 2:
+                for i in range(B):
+                    if bw1[i] != bw0[i] and bw1[i]: assert b.set_bandwidth(i, bw1[i]) == 0
+            b.encode_device(ins[k], 16, T, outs[k], stride, hip_stream=None, sync=not ready)
+            if not ready: recs.append(b.last_records(T).view(np.int32)[:, :, 74].copy())
+        d.sync()
+        got = np.concatenate([d.get(outs[k], (B, T, stride), np.uint8) for k in range(K)], axis=1)
+        assert not b.last_status(T).any()
+        bad, badbw = [], []
+        for i in range(B):
+            o = Oracle(fs, 1, ms, 0, br[i], portable_math=True, bandwidth=bw0[i])
+            tr = o.enable_trace()
+            for t in range(T * K):
+                if t == 2 * T and bw1[i] != bw0[i] and bw1[i]: assert o.set_bandwidth(bw1[i]) == 0
+                w = o.encode(pcm[i, t][None])
+                if (got[i, t, :len(w)] != w).any(): bad.append((i, t))
+                if recs and recs[t // T][i, t % T] != tr[0].bw_idx: badbw.append((i, t, int(recs[t // T][i, t % T]), tr[0].bw_idx))
+        assert not bad, (len(bad), bad[:8])
+        assert not badbw, badbw[:8]
+        # the limited streams really are band limited: a 4 kHz stream's frames differ from the unlimited encode of the same PCM
+        o = Oracle(fs, 1, ms, 0, br[1], portable_math=True)
+        assert any((got[1, t, :o.nbytes] != o.encode(pcm[1, t][None])).any() for t in range(T))
+    finally:
+        d.free()

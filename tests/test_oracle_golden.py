@@ -76,3 +76,32 @@ def test_decoder_golden(portable):
         got, st = oracle_decode_streams(frames, nbytes, bfi, fs, ms, hr, ch, portable_math=portable)
         assert (st == status).all(), tag
         assert (got == pcm).all(), (tag, np.argwhere((got != pcm).any(axis=(2, 3)))[:3].tolist())
+
+
+ETSI_WAV = "/root/reference/LC3plus_ETSI_src_v17171_20200723/testvec/input/thetest48.wav"
+
+
+@pytest.mark.skipif(not os.path.exists(ETSI_WAV), reason="the reference's test vector is only mounted in the build container")
+def test_config0_full_length_bitstream_md5():
+    """BASELINE configs[0] / SURVEY 8(d) config 1 at FULL length: E/testvec/input/thetest48.wav (484 191 samples = 1008 whole frames + a partial one, which
+    the reference's CLI pads with zeros: 1009 frames) at 64 kbps through the oracle (glibc math, i.e. the build that is byte-identical to the compiled
+    reference).  (1) The 1008 whole frames against the digest tests/golden/make_golden.py took from the unmodified ETSI encoder's bitstream of the same
+    PCM; (2) all 1009 frames, the zero-padded last one included, byte for byte against the compiled reference run live (oracle/_ref, when built).  The WAV
+    itself is not copied into the repo: the fixture holds its first 64 frames plus the md5 of the PCM and of the full bitstream."""
+    import hashlib, wave
+    from lc3_harness import have_ref, ref_encode_streams
+    g = load("c0_thetest48_64k_first64")
+    w = wave.open(ETSI_WAV)
+    x = np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16)
+    T = x.size // 480
+    assert T == int(g["full_frames"]) == 1008 and x.size % 480 != 0
+    padded = np.zeros((T + 1) * 480, np.int16); padded[:x.size] = x
+    pcm = padded.reshape(1, T + 1, 480)
+    assert hashlib.md5(pcm[:, :T].tobytes()).hexdigest() == str(g["full_pcm_md5"])
+    out = oracle_encode_streams(pcm, 48000, 10.0, 0, [64000])[0]
+    assert out.shape == (1009, 80)
+    assert hashlib.md5(out[:T].tobytes()).hexdigest() == str(g["full_bitstream_md5"])
+    assert (out[:64] == g["frames"][0]).all()
+    if have_ref():
+        ref = ref_encode_streams(pcm, 48000, 10.0, 0, [64000])[0]
+        assert (ref == out).all(), np.where((ref != out).any(axis=1))[0][:4]

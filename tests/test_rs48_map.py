@@ -14,3 +14,15 @@ def test_rs48_map_is_a_conflict_free_permutation():
     bank = lambda n: math.ceil(15 * n / 4) % 32                               # first input sample of output n (R/resamp12k8.c:48-57), LDS bank of a dword
     for g in (n0[:32], n0[32:], n1[:32], n1[32:]):
         assert len({bank(n) for n in g}) == 32
+
+
+def test_rs48_lane4_table_is_the_generated_conflict_free_one():
+    """lc3t_rs48_lane4 (lc3_enc_resample48_kernel): a permutation of (frame, b, p) codes whose sixteen lanes of every ds_read_b128 service group read sixteen
+    different quad-words mod 16 - equal to what tools/rs48_map4.py builds"""
+    import importlib.util
+    src = open(os.path.join(ROOT, "audio_codec_amd", "csrc", "lc3_enc_pre.inc")).read()
+    m = re.search(r"lc3t_rs48_lane4\[64\] = \{([^}]*)\}", src)
+    v = [int(x) for x in m.group(1).replace("\n", " ").split(",")]
+    spec = importlib.util.spec_from_file_location("rs48_map4", os.path.join(ROOT, "tools", "rs48_map4.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    assert mod.conflict_free(v) and v == mod.build()

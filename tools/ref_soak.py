@@ -17,8 +17,12 @@ from lc3_harness import synth_pcm, mld_between, have_ref, MLD_TOOL
 REF_BENCH = os.path.join(ROOT, "oracle", "_ref", "cpu_bench_ref")
 RATES12 = [16000, 24000, 32000, 48000, 64000, 80000, 96000, 128000, 160000, 192000, 256000, 320000]
 # name: fs, ms, hr, channels, N, rates, streams, frames  (BASELINE.json configs[0..4] shapes; c0 = the reference's own mono case on synthetic PCM)
+# "bw" configurations (E/conformance/lc3_conformance.py:803-817,850-862 band_limiting / bandwidth_switching): a bandwidth set per stream at the start
+# (a third of the streams), switched at the call boundary (a ninth), band-limited input (an eighth); 32 kHz / 5 ms is the second shape of VERDICT r3 item 3
 CONFIGS = [
     ("c0", 48000, 10.0, 0, 1, 480, [64000], 64, 1009),
+    ("b1", 48000, 10.0, 0, 1, 480, [64000, 92000], 2048, 64),
+    ("b2", 32000, 5.0, 0, 1, 160, [64000, 128000], 1024, 64),
     ("c1", 48000, 10.0, 0, 1, 480, [64000], 4096, 64),
     ("c3", 48000, 10.0, 0, 2, 480, [128000], 2048, 64),
     ("c4", 96000, 2.5, 1, 1, 240, [256000], 2048, 128),
@@ -26,15 +30,18 @@ CONFIGS = [
 ]
 
 
-def ref_encode(pcm, fs, ms, hr, ch, rate, nbytes_total):
+def ref_encode(pcm, fs, ms, hr, ch, rate, nbytes_total, plan=None):
     """pcm [S, T, ch, N] int16 -> [S, T, nbytes_total] uint8 by the compiled reference, all host cores."""
     S, T = pcm.shape[:2]
     with tempfile.TemporaryDirectory(prefix="refsoak_") as td:
         pin, pout = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
         np.ascontiguousarray(pcm).tofile(pin)
         thr = max(1, min(os.cpu_count() or 1, 64))
+        env = dict(os.environ)
+        if plan is not None and plan.any():
+            np.ascontiguousarray(plan, np.int32).tofile(os.path.join(td, "bw.bin")); env["LC3_BENCH_BW_PLAN"] = os.path.join(td, "bw.bin")
         r = subprocess.run([REF_BENCH, "enc", str(fs), str(ms), str(hr), str(ch), str(rate), str(S), str(T), str(thr), pin, pout],
-                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=3000)
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=3000, env=env)
         if r.returncode: raise RuntimeError(r.stderr[-300:])
         return np.fromfile(pout, np.uint8).reshape(S, T, nbytes_total)
 
@@ -49,14 +56,23 @@ def run(scale=1.0, verbose=True):
         br = [rates[i % len(rates)] for i in range(S)]
         b = audio_codec_amd.Batch(S, fs, ch, ms, hr, br, device=0)
         h = T // 2
-        got = np.concatenate([b.encode(pcm[:, :h] if ch > 1 else pcm[:, :h, 0]), b.encode(pcm[:, h:] if ch > 1 else pcm[:, h:, 0])], axis=1)   # two calls: state persists
+        plan = np.zeros((S, T), np.int32)
+        if name[0] == "b":
+            import soak
+            lp = [i for i in range(S) if i % 8 == 5]
+            pcm[:, :, 0] = soak.band_limit(pcm[:, :, 0], fs, lp, [(4000, 8000, 12000, 16000)[(i // 8) % 4] for i in lp])
+            plan = soak.bandwidth_plan(S, T, fs, hr, [h], 5)
+            for i in np.nonzero(plan[:, 0])[0]: assert b.set_bandwidth(int(i), int(plan[i, 0])) in (0, 18)
+        g1 = b.encode(pcm[:, :h] if ch > 1 else pcm[:, :h, 0])
+        for i in np.nonzero(plan[:, h])[0]: assert b.set_bandwidth(int(i), int(plan[i, h])) in (0, 18)
+        got = np.concatenate([g1, b.encode(pcm[:, h:] if ch > 1 else pcm[:, h:, 0])], axis=1)   # two calls: state persists
         nbs = [b.num_bytes(i) for i in range(S)]
         b.close()
         diff = tot = 0; worst = None; nstreams_diff = 0
         for rate in sorted(set(br)):
             idx = [i for i in range(S) if br[i] == rate]
             nb = nbs[idx[0]]
-            want = ref_encode(pcm[idx], fs, ms, hr, ch, rate, nb)
+            want = ref_encode(pcm[idx], fs, ms, hr, ch, rate, nb, plan[idx])
             g = got[idx][:, :, :nb]
             neq = (g != want).any(axis=2)
             diff += int(neq.sum()); tot += neq.size * ch

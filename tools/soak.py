@@ -9,8 +9,35 @@ from lc3_harness import synth_pcm, ORACLE_DIR
 
 L = C.CDLL(os.path.join(ORACLE_DIR, "liblc3_oracle_pm.so"))
 L.lc3o_encode_batch16.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+L.lc3o_encode_batch16_bw.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+BW = int(os.environ.get("SOAK_BW", "1"))                  # the bandwidth column (E/conformance/lc3_conformance.py:803-817,850-862): band-limited input, set and switched bandwidths
 READY = int(os.environ.get("SOAK_READY", "0"))            # frames per call of the overlapped variant (0: host-pointer calls)
 HIP = C.CDLL("libamdhip64.so") if READY else None
+
+
+def band_limit(pcm, fs, streams, fcs):
+    """low-pass the given streams (windowed-sinc FIR): the conformance procedure's band-limited items, which the bandwidth DETECTOR has to find"""
+    out = pcm.copy()
+    for s, fc in zip(streams, fcs):
+        n = np.arange(-64, 65)
+        h = np.sinc(2.0 * fc / fs * n) * (2.0 * fc / fs) * np.hamming(n.size)
+        x = np.convolve(pcm[s].reshape(-1).astype(np.float64), h, mode="same")
+        out[s] = np.clip(np.rint(x), -32768, 32767).astype(np.int16).reshape(pcm[s].shape)
+    return out
+
+
+def bandwidth_plan(B, T, fs, hr, cuts, seed):
+    """int32 [B, T]: bandwidth to set in front of frame t (0 = keep).  A third of the streams set one at the start, a third of those switch at every
+    call boundary (the GPU batch switches between calls, the oracle at the same frames)."""
+    plan = np.zeros((B, T), np.int32)
+    allowed = [bw for bw in (4000, 8000, 12000, 16000, 20000) if 2 * bw <= min(fs, 40000)]
+    if hr or fs < 16000 or not allowed: return plan
+    rng = np.random.default_rng(77 + seed)
+    for i in range(B):
+        if i % 3 == 1: plan[i, 0] = allowed[rng.integers(len(allowed))]
+        if i % 9 == 4:
+            for t in cuts: plan[i, t] = allowed[rng.integers(len(allowed))]
+    return plan
 
 
 def encode_ready(b, pcm, tc):
@@ -56,13 +83,21 @@ def run(NS, B, T, verbose=True):
         for seed in range(NS):
             br = np.array([rates[(i + seed) % len(rates)] for i in range(B)], np.int32)
             pcm = synth_pcm(B, T, N, fs, seed=4000 + 17 * seed)
+            plan = np.zeros((B, T), np.int32)
+            if BW and not READY:
+                lp = [i for i in range(B) if i % 8 == 5]
+                pcm = band_limit(pcm, 48000 if fs == 44100 else fs, lp, [(4000, 8000, 12000, 16000)[(i // 8) % 4] for i in lp])
+                plan = bandwidth_plan(B, T, fs, hr, [T // 3], seed)
             b = audio_codec_amd.Batch(B, fs, 1, ms, hr, list(map(int, br)), device=0)
             if READY:     # device pointers, the input-ready promise, calls of READY frames queued back to back (consecutive calls overlap)
                 got = encode_ready(b, pcm, READY)
             else:
-                got = np.concatenate([b.encode(pcm[:, :T // 3]), b.encode(pcm[:, T // 3:])], axis=1)
+                for i in np.nonzero(plan[:, 0])[0]: assert b.set_bandwidth(int(i), int(plan[i, 0])) in (0, 18)
+                g1 = b.encode(pcm[:, :T // 3])
+                for i in np.nonzero(plan[:, T // 3])[0]: assert b.set_bandwidth(int(i), int(plan[i, T // 3])) in (0, 18)
+                got = np.concatenate([g1, b.encode(pcm[:, T // 3:])], axis=1)
             want = np.zeros_like(got)
-            rc = L.lc3o_encode_batch16(fs, ms, hr, B, T, br.ctypes.data, np.ascontiguousarray(pcm).ctypes.data, want.ctypes.data, b.stride)
+            rc = L.lc3o_encode_batch16_bw(fs, ms, hr, B, T, br.ctypes.data, np.ascontiguousarray(plan).ctypes.data, np.ascontiguousarray(pcm).ctypes.data, want.ctypes.data, b.stride)
             assert rc == 0, rc
             nb = np.array([b.num_bytes(i) for i in range(B)])
             d = sum(int((got[i, :, :nb[i]] != want[i, :, :nb[i]]).any(axis=1).sum()) for i in range(B))
