@@ -25,6 +25,7 @@
 #include <stddef.h>
 
 #define LC3T_QUAL static __device__ const
+#include "lc3_fastmath.h"
 #include "lc3_tables.h"
 #include "lc3_plan.h"
 #include "lc3_shim.h"
@@ -143,11 +144,13 @@ enum { I_OLPA_PITCH = 0, I_LTPF_ON, I_ATT_POS, I_ATT_FLAG, I_MEM_TARGET, I_MEM_S
 /* ------------------------------------------------------------------------------------------------ */
 /* small helpers                                                                                     */
 /* ------------------------------------------------------------------------------------------------ */
-__device__ __forceinline__ float m_log2f(float x) { return (float)log2((double)x); }
-__device__ __forceinline__ float m_log10f(float x) { return (float)log10((double)x); }
+/* (float)f((double)x) for f = log2, log10, 2^x: lc3_fastmath.h - a dozen double-precision fused multiply-adds behind a table, bit-identical to glibc's
+ * log2 / log10 / exp2 / pow(2, .) for EVERY float argument (tools/fastmath_check.c), instead of the device library's 40 ... 80 fp64 instructions.  The
+ * one-frame-per-lane kernels read the tables from LDS copies (m_*_t), everything else from global memory (a gather per call). */
+__device__ __forceinline__ float m_log2f(float x) { return lc3m_log2f(x, lc3m_log2_tab); }
+__device__ __forceinline__ float m_log10f(float x) { return lc3m_log10f(x, lc3m_log10_tab); }
 __device__ __forceinline__ float m_powf(float x, float y) { return (float)pow((double)x, (double)y); }
-/* powf(2, y): the same value from the much shorter exp2 (both are far inside half an ulp of a double before the rounding to float) */
-__device__ __forceinline__ float m_pow2f(float y) { return (float)exp2((double)y); }
+__device__ __forceinline__ float m_pow2f(float y) { return lc3m_exp2f(y, lc3m_exp2_tab); }
 __device__ __forceinline__ float mul_d(float a, double c) { return (float)((double)a * c); }
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }

@@ -1,0 +1,69 @@
+/* tools/fastmath_check.c -- TEST INFRASTRUCTURE: audio_codec_amd/csrc/lc3_fastmath.h against glibc for EVERY float argument.
+ *   gcc -O2 -ffp-contract=off -mfma -pthread -Iaudio_codec_amd/csrc tools/fastmath_check.c -o /tmp/fastmath_check -lm
+ *   /tmp/fastmath_check [threads] [stride]      stride 1 = exhaustive (about 6.4e9 evaluations), stride n = every n-th bit pattern
+ * log2 / log10: all positive finite floats (subnormals included); exp2: all floats in [-160, 160] (beyond that both sides give 0 / inf, checked at the
+ * ends), once against exp2 and once against pow(2, x), which is what the oracle calls.  Prints the number of arguments whose results differ in any bit and the first of them.  Exit code 1 when anything differs. */
+#define _GNU_SOURCE
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "lc3_fastmath.h"
+
+typedef struct { int fn; uint32_t lo, hi, stride; unsigned long long n, bad; uint32_t first[8]; } job_t;
+static float asf(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static uint32_t asu(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static void* work(void* a)
+{
+    job_t* j = (job_t*)a;
+    for (uint64_t u = j->lo; u < j->hi; u += j->stride) {
+        const float x = asf((uint32_t)u);
+        float got, want;
+        if (j->fn == 0) { got = lc3m_log2f(x, lc3m_log2_tab); want = (float)log2((double)x); }
+        else if (j->fn == 1) { got = lc3m_log10f(x, lc3m_log10_tab); want = (float)log10((double)x); }
+        else if (j->fn == 2) { got = lc3m_exp2f(x, lc3m_exp2_tab); want = (float)exp2((double)x); }
+        else { got = lc3m_exp2f(x, lc3m_exp2_tab); want = (float)pow(2.0, (double)x); }      /* what oracle/lc3_oracle.c's m_powf(2, x) evaluates */
+        j->n++;
+        if (asu(got) != asu(want)) { if (j->bad < 8) j->first[j->bad] = (uint32_t)u; j->bad++; }
+    }
+    return 0;
+}
+int main(int argc, char** argv)
+{
+    const int P = argc > 1 ? atoi(argv[1]) : 8;
+    const uint32_t stride = argc > 2 ? (uint32_t)atoi(argv[2]) : 1;
+    static const char* name[4] = {"log2", "log10", "exp2", "pow2"};
+    int rc = 0;
+    for (int fn = 0; fn < 4; fn++) {
+        /* bit-pattern ranges: logs 0x00000001 ... 0x7F7FFFFF; exp2: +0 ... 160.0 and -0 ... -160.0 */
+        uint32_t ranges[2][2]; int nr = 1;
+        if (fn < 2) { ranges[0][0] = 1; ranges[0][1] = 0x7F800000u; }
+        else { ranges[0][0] = 0; ranges[0][1] = asu(160.0f) + 1; ranges[1][0] = 0x80000000u; ranges[1][1] = asu(-160.0f) + 1; nr = 2; }
+        unsigned long long n = 0, bad = 0; uint32_t first[8]; int nf = 0;
+        for (int q = 0; q < nr; q++) {
+            pthread_t th[64]; job_t jobs[64];
+            const uint64_t span = (uint64_t)ranges[q][1] - ranges[q][0];
+            for (int i = 0; i < P; i++) {
+                memset(&jobs[i], 0, sizeof jobs[i]);
+                jobs[i].fn = fn; jobs[i].stride = stride;
+                jobs[i].lo = (uint32_t)(ranges[q][0] + span * i / P); jobs[i].hi = (uint32_t)(ranges[q][0] + span * (i + 1) / P);
+                pthread_create(&th[i], 0, work, &jobs[i]);
+            }
+            for (int i = 0; i < P; i++) {
+                pthread_join(th[i], 0); n += jobs[i].n; bad += jobs[i].bad;
+                for (unsigned b = 0; b < jobs[i].bad && b < 8 && nf < 8; b++) first[nf++] = jobs[i].first[b];
+            }
+        }
+        printf("%-5s: %llu arguments, %llu differ from glibc", name[fn], n, bad);
+        for (int i = 0; i < nf; i++) printf(" %08x", first[i]);
+        printf("\n"); fflush(stdout);
+        if (bad) rc = 1;
+    }
+    /* the arguments that take the library path on both sides */
+    const float sp[] = {0.0f, -0.0f, -1.0f, 1.0f / 0.0f, -1.0f / 0.0f, 0.0f / 0.0f, 1e30f, -1e30f, 161.0f, -161.0f, 1024.0f, -1100.0f};
+    for (unsigned i = 0; i < sizeof sp / sizeof sp[0]; i++) {
+        const float a = lc3m_log2f(sp[i], lc3m_log2_tab), b = (float)log2((double)sp[i]), c = lc3m_exp2f(sp[i], lc3m_exp2_tab), d = (float)exp2((double)sp[i]);
+        if ((asu(a) != asu(b) && !(a != a && b != b)) || (asu(c) != asu(d) && !(c != c && d != d))) { printf("special argument %g differs\n", (double)sp[i]); rc = 1; }
+    }
+    return rc;
+}
