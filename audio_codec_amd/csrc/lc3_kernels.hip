@@ -2912,8 +2912,9 @@ struct lc3hip_ctx {
     lc3d_plan* d_plan; lc3d_chan* d_chans; float* d_state;
     void* d_pcm; size_t pcm_cap; uint8_t* d_out; size_t out_cap;
     lc3d_trace* d_trace; size_t trace_cap;
-    int* d_dump; size_t dump_cap; int hr, fused; float* d_y12[LC3D_SETS]; size_t y12_cap[LC3D_SETS];
-    uint8_t* d_status; size_t status_cap; int status_frames;
+    int* d_dumpv[LC3D_SETS]; size_t dump_capv[LC3D_SETS]; int hr, fused; float* d_y12[LC3D_SETS]; size_t y12_cap[LC3D_SETS];
+    uint8_t* d_status; uint8_t* d_statusv[LC3D_SETS]; size_t status_capv[LC3D_SETS]; int status_frames;      /* d_status: the set of the last call */
+    hipStream_t s_pk[2]; hipEvent_t ev_pk[2]; int pk_par;       /* the bitstream writers of consecutive calls beside each other (enc_launch) */
     float* d_spec[LC3D_SETS]; size_t spec_cap[LC3D_SETS]; float* d_frec[LC3D_SETS]; size_t frec_cap[LC3D_SETS]; hipEvent_t ev_done[LC3D_SETS]; float* d_xnext[LC3D_SETS + 1]; int xn_par, row_par; uint8_t* h_attack; int any_attack;
     int input_ready, ahead_ok, ahead_T, ahead_R;   /* lc3hip_set_input_ready: side kernels of a call beside the previous call's tail */   /* split path (lc3_enc_front.inc) */      /* per channel-frame status bits of the last call (LC3D_ENC_ST_*) */
     /* host-pointer pipeline (lc3hip_encode_host): two chunk slots, each with device staging and (for pageable callers) pinned staging */
@@ -3027,6 +3028,7 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
      * 80 bytes whatever the batch size): up to LC3D_FUSED_MAX_T frames per call the wave-parallel writer inside the first kernel
      * (st_bitstream, ~6 us per frame) is used instead - the single-stream lc3_enc_* API and T = 1 batches live here. */
     int* ddump = nullptr; int dstride = 0;
+    const int set = c->input_ready ? c->row_par : 0;        /* the set of hand-over buffers of this call (rows, records, writer scratch, status bytes) */
     /* with the input-ready promise consecutive short calls overlap on the pipelined path, which then wins from 4 frames per call
      * (4096 streams, Mframes/s pipelined / in-kernel writer: 3 frames 31.9 / 36.3, 4: 39.8 / 38.0, 6: 48.6 / 40.2, 8: 53.9 / 41.2; without the
      * promise 8: 40.2 / 41.2) */
@@ -3034,8 +3036,8 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
     if (!in_kernel_writer) {
         dstride = PK_STRIDE(c->N, c->hr);
         const size_t need = (size_t)c->ncs * dT * dstride;
-        if (c->dump_cap < need) { if (c->d_dump) HIPCHK(hipFree(c->d_dump)); c->d_dump = nullptr; c->dump_cap = 0; HIPCHK(hipMalloc((void**)&c->d_dump, need * sizeof(int))); c->dump_cap = need; }
-        ddump = c->d_dump;
+        if (c->dump_capv[set] < need) { if (c->d_dumpv[set]) HIPCHK(hipFree(c->d_dumpv[set])); c->d_dumpv[set] = nullptr; c->dump_capv[set] = 0; HIPCHK(hipMalloc((void**)&c->d_dumpv[set], need * sizeof(int))); c->dump_capv[set] = need; }
+        ddump = c->d_dumpv[set];
     }
     /* ahead of it: the 12.8 kHz resampler of all frames at once and its HP50 recurrence one stream per lane (lc3_enc_pre.inc) */
     float* dy12 = nullptr;
@@ -3045,15 +3047,17 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
         if (c->y12_cap[yb] < need) { if (c->d_y12[yb]) HIPCHK(hipFree(c->d_y12[yb])); c->d_y12[yb] = nullptr; c->y12_cap[yb] = 0; HIPCHK(hipMalloc((void**)&c->d_y12[yb], need * sizeof(float))); c->y12_cap[yb] = need; }
         dy12 = c->d_y12[yb];
     }
-    if (dt0 == 0) {   /* per channel-frame status bits (LC3D_ENC_ST_*), cleared per call */
-        const size_t need = (size_t)c->ncs * dT;
-        if (c->status_cap < need) { if (c->d_status) HIPCHK(hipFree(c->d_status)); c->d_status = nullptr; c->status_cap = 0; HIPCHK(hipMalloc((void**)&c->d_status, need)); c->status_cap = need; }
-        HIPCHK(hipMemsetAsync(c->d_status, 0, need, s));
-        c->status_frames = dT;
-    }
     static int split_off = -1;
     if (split_off < 0) { const char* e = getenv("LC3PLUS_ENC_NO_SPLIT"); split_off = e && e[0] == '1'; }
     const bool split = dy12 && ddump && !split_off;
+    if (dt0 == 0) {   /* per channel-frame status bits (LC3D_ENC_ST_*), cleared per call: by the stream that runs the kernel that sets them (the writer's, on the pipelined path) */
+        const size_t need = (size_t)c->ncs * dT;
+        if (c->status_capv[set] < need) { if (c->d_statusv[set]) HIPCHK(hipFree(c->d_statusv[set])); c->d_statusv[set] = nullptr; c->status_capv[set] = 0; HIPCHK(hipMalloc((void**)&c->d_statusv[set], need)); c->status_capv[set] = need; }
+        c->d_status = c->d_statusv[set];
+        if (!split) HIPCHK(hipMemsetAsync(c->d_status, 0, need, s));
+        c->status_frames = dT;
+    }
+    bool rate_on_side = false;
     float* rows_for_pack = nullptr; const float* frec_for_pack = nullptr;      /* pipelined path: the bitstream writer starts from the shaped spectra (frame-parallel tail, one frame per lane) */
     const int mc = c->big ? LC3D_MEMCAP_BIG : LC3D_MEMCAP_STD;
     if (!split) {
@@ -3078,7 +3082,7 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
         /* spectrum rows and records of all dT frames of the call (a call through host pointers comes in pieces: rows dt0 ...): two sets under
          * the input-ready promise (consecutive calls overlap: the side kernels of a call write one set while the bitstream writer of the call
          * before still reads the other), one otherwise */
-        const int hb_ = c->input_ready ? c->row_par : 0;
+        const int hb_ = set;
         const size_t ns = (size_t)c->ncs * dT * c->srow, nr = (size_t)c->ncs * dT * FR_WORDS;
         if (c->spec_cap[hb_] < ns) { if (c->d_spec[hb_]) HIPCHK(hipFree(c->d_spec[hb_])); c->d_spec[hb_] = nullptr; c->spec_cap[hb_] = 0; HIPCHK(hipMalloc((void**)&c->d_spec[hb_], ns * sizeof(float))); c->spec_cap[hb_] = ns; }
         if (c->frec_cap[hb_] < nr) { if (c->d_frec[hb_]) HIPCHK(hipFree(c->d_frec[hb_])); c->d_frec[hb_] = nullptr; c->frec_cap[hb_] = 0; HIPCHK(hipMalloc((void**)&c->d_frec[hb_], nr * sizeof(float))); c->frec_cap[hb_] = nr; }
@@ -3091,6 +3095,7 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
               if (e && atoi(e) >= 5) { HIPCHK(hipStreamCreateWithFlags(&c->s_pit, hipStreamNonBlocking)); HIPCHK(hipStreamCreateWithFlags(&c->s_ln, hipStreamNonBlocking)); } }
             for (int i = 0; i < LC3D_MAX_RUNS; i++) { HIPCHK(hipEventCreateWithFlags(&c->ev_h[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_m[i], hipEventDisableTiming)); }
             c->s_rt = NULL;
+            for (int i = 0; i < 2; i++) { c->s_pk[i] = NULL; HIPCHK(hipEventCreateWithFlags(&c->ev_pk[i], hipEventDisableTiming)); }
             HIPCHK(hipEventCreateWithFlags(&c->ev_rate, hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
             for (int i = 0; i < LC3D_SETS; i++) HIPCHK(hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming));
@@ -3214,7 +3219,7 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
             else DUPL('s') hipLaunchKernelGGL(lc3_enc_rate_kernel, dim3((unsigned)((c->ncs + RATE_WG - 1) / RATE_WG)), dim3(RATE_WG * WAVE), 0, rs, c->d_plan, c->d_chans, c->d_state, dT, dt0 + tb, nt, c->ncs, dspec, c->srow, dfrec, xn_w, last);
             HIPCHK(hipGetLastError());
         }
-        HIPCHK(hipEventRecord(c->ev_rate, rs)); c->rate_armed = 1;
+        HIPCHK(hipEventRecord(c->ev_rate, rs)); c->rate_armed = 1; rate_on_side = rs != s;
         if (rs != s) HIPCHK(hipStreamWaitEvent(s, c->ev_rate, 0));      /* the writer (and whatever the caller queues next) behind the rate chain */
         c->ahead_ok = (dt0 == 0 && dT == n_frames && pack) ? 1 : 0; c->ahead_T = n_frames; c->ahead_R = R;
         c->xn_par = (c->xn_par + 1) % (LC3D_SETS + 1);
@@ -3225,9 +3230,29 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
         if (!wpg) { const char* e = getenv("LC3PLUS_ENC_PACK_WPG"); wpg = e && atoi(e) >= 1 && atoi(e) <= 4 ? atoi(e) : 4; }     /* diagnostic */
         const size_t per_wave = (size_t)PK_XBUF * WAVE * sizeof(unsigned);
         const long long tasks = (long long)c->ncs * dT, per_wg = (long long)wpg * WAVE;
-        DUPL('k') hipLaunchKernelGGL(lc3_enc_pack_kernel, dim3((unsigned)((tasks + per_wg - 1) / per_wg)), dim3(wpg * WAVE), per_wave * wpg, s, c->d_plan, c->d_chans, ddump, dstride,
+        /* The writer codes one frame per lane: its duration is the latency of the LARGEST frame of the batch (c5: 1.7 ms for 400 bytes, c96: 3.2 ms), whatever the
+         * batch size, and on the caller's stream the writers of consecutive calls run one after the other.  Where that is the longest stream (the rule that moves the
+         * rate chain off the caller's stream: large frames, short calls) and calls overlap, the writers CAN alternate between two side streams - writer k + 1 beside
+         * writer k, each with its own set of scratch rows and status bytes, the caller's stream waiting for their events in call order.  Measured (Mframes/s,
+         * off / on): with HIP's default four hardware queues c5 87.0 / 80.0, c96 32.1 / 28.7, c3 85.1 / 73.0 - six streams share four queues and kernels of two
+         * streams on one queue run back to back; with GPU_MAX_HW_QUEUES=8 c5 90.9 / 92.4, c96 28.8 / 33.9, c3 85.5 / 85.8.  So it is a deployment switch
+         * (LC3PLUS_ENC_PACK_STREAM=1 together with GPU_MAX_HW_QUEUES >= 6), off by default. */
+        static int pk_env = -2;
+        if (pk_env == -2) { const char* e = getenv("LC3PLUS_ENC_PACK_STREAM"); pk_env = !e ? -1 : e[0] == '1' ? 1 : e[0] == '0' ? 0 : -1; }     /* diagnostic */
+        const bool side = split && rate_on_side && c->input_ready && dt0 == 0 && dT == n_frames && pk_env == 1;
+        hipStream_t ps = s;
+        if (side) {
+            /* behind this call's rate chain only - NOT behind the caller's stream, whose tail is the writer of the call before: under the input-ready promise the
+             * output buffer of a call, like its PCM, is the caller's to have ready (include/lc3plus_batch.h) */
+            if (!c->s_pk[c->pk_par]) HIPCHK(hipStreamCreateWithFlags(&c->s_pk[c->pk_par], hipStreamNonBlocking));
+            ps = c->s_pk[c->pk_par];
+            HIPCHK(hipStreamWaitEvent(ps, c->ev_rate, 0));
+        }
+        if (split) HIPCHK(hipMemsetAsync(c->d_status, 0, (size_t)c->ncs * dT, ps));
+        DUPL('k') hipLaunchKernelGGL(lc3_enc_pack_kernel, dim3((unsigned)((tasks + per_wg - 1) / per_wg)), dim3(wpg * WAVE), per_wave * wpg, ps, c->d_plan, c->d_chans, ddump, dstride,
                            dT, 0, dT, c->ncs, dout, out_stride, c->d_status, rows_for_pack, c->srow, frec_for_pack);
-        if (split && c->input_ready) { HIPCHK(hipEventRecord(c->ev_done[c->row_par], s)); c->row_par = (c->row_par + 1) % LC3D_SETS; }      /* this call's set of rows and records is free again */
+        if (split && c->input_ready) { HIPCHK(hipEventRecord(c->ev_done[c->row_par], ps)); c->row_par = (c->row_par + 1) % LC3D_SETS; }      /* this call's set of rows and records is free again */
+        if (side) { HIPCHK(hipEventRecord(c->ev_pk[c->pk_par], ps)); HIPCHK(hipStreamWaitEvent(s, c->ev_pk[c->pk_par], 0)); c->pk_par ^= 1; }
     }
     HIPCHK(hipGetLastError());
     c->last_stream = s;
@@ -3411,10 +3436,9 @@ extern "C" int lc3hip_destroy(void* ctx)
     if (c->d_state) hipFree(c->d_state);
     if (c->d_pcm) hipFree(c->d_pcm);
     if (c->d_out) hipFree(c->d_out);
-    if (c->d_dump) hipFree(c->d_dump);
+    for (int i = 0; i < LC3D_SETS; i++) { if (c->d_dumpv[i]) hipFree(c->d_dumpv[i]); if (c->d_statusv[i]) hipFree(c->d_statusv[i]); }
     for (int i = 0; i < LC3D_SETS; i++) if (c->d_y12[i]) hipFree(c->d_y12[i]);
     if (c->d_trace) hipFree(c->d_trace);
-    if (c->d_status) hipFree(c->d_status);
     for (int i = 0; i < LC3D_SETS; i++) { if (c->d_spec[i]) hipFree(c->d_spec[i]); if (c->d_frec[i]) hipFree(c->d_frec[i]); }
     for (int i = 0; i < LC3D_SETS + 1; i++) if (c->d_xnext[i]) hipFree(c->d_xnext[i]);
     free(c->h_attack); free(c->h_nb);
@@ -3425,7 +3449,7 @@ extern "C" int lc3hip_destroy(void* ctx)
         if (c->ev_k[i]) hipEventDestroy(c->ev_k[i]);
     }
     if (c->s_h2d) hipStreamDestroy(c->s_h2d);
-    if (c->s_pre) { if (c->s_pit != c->s_pre) { hipStreamDestroy(c->s_pit); hipStreamDestroy(c->s_ln); } hipStreamDestroy(c->s_pre); hipStreamDestroy(c->s_fr); if (c->s_rt) hipStreamDestroy(c->s_rt); hipEventDestroy(c->ev_rate);
+    if (c->s_pre) { if (c->s_pit != c->s_pre) { hipStreamDestroy(c->s_pit); hipStreamDestroy(c->s_ln); } hipStreamDestroy(c->s_pre); hipStreamDestroy(c->s_fr); if (c->s_rt) hipStreamDestroy(c->s_rt); for (int i = 0; i < 2; i++) { if (c->s_pk[i]) hipStreamDestroy(c->s_pk[i]); hipEventDestroy(c->ev_pk[i]); } hipEventDestroy(c->ev_rate);
                     for (int i = 0; i < LC3D_MAX_RUNS; i++) { hipEventDestroy(c->ev_h[i]); hipEventDestroy(c->ev_m[i]); } hipEventDestroy(c->ev_fork); for (int i = 0; i < LC3D_SETS; i++) hipEventDestroy(c->ev_done[i]);
                     for (int i = 0; i < LC3D_MAX_RUNS; i++) { hipEventDestroy(c->ev_p[i]); hipEventDestroy(c->ev_f[i]); } }
     if (c->ev0) hipEventDestroy(c->ev0);

@@ -56,7 +56,9 @@ LC3_Error lc3plus_enc_batch_set_state(lc3plus_batch* batch, const void* state, s
  * that a kernel or copy queued on hip_stream is still producing).  The batch then lets the frame-parallel and pitch kernels of a
  * call start on its own streams while the sequential tail and the bitstream writer of the previous call on the same hip_stream are
  * still running (consecutive calls of equal n_frames of up to 256 frames; up to three calls are then in flight); results are identical, and the output of a call is complete in stream order
- * on hip_stream as before.  Streaming servers that fill their PCM ring ahead of the encode calls are the use. */
+ * on hip_stream as before.  The promise covers the OUTPUT buffer as well: it must be free to be written when the call is made - not still being read by work
+ * queued earlier on hip_stream - because the bitstream writers of consecutive calls may run beside each other (large frames, short calls), each into the
+ * buffer of its own call.  Streaming servers that fill their PCM ring ahead of the encode calls and drain their output ring behind them are the use. */
 LC3_Error lc3plus_enc_batch_set_input_ready(lc3plus_batch* batch, int ready);
 
 /* Kernel-only timing of the last encode() call in milliseconds (HIP events on the launch stream). */
