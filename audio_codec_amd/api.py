@@ -175,8 +175,11 @@ class Batch:
         w = self.lib.lc3plus_enc_batch_record_words()
         rec = np.zeros((self.n_streams * self.channels, T, w), dtype=np.float32)
         n = self.lib.lc3plus_enc_batch_last_records(self.h, rec.ctypes.data, rec.size)
+        if n == 0:
+            raise LC3Error(1, "lc3plus_enc_batch_last_records: the last call did not take the pipelined path (it had at most 8 frames - 5 under the input-ready "
+                              "promise - or was traced), so it left no records")
         if n != rec.size:
-            raise LC3Error(1, "lc3plus_enc_batch_last_records (%d of %d words)" % (n, rec.size))
+            raise LC3Error(1, "lc3plus_enc_batch_last_records (%d of %d words: T does not match the last call)" % (n, rec.size))
         return rec
 
     def encode_traced(self, pcm, bitdepth=16):

@@ -1,10 +1,12 @@
-/* lc3_kernels.hip -- gfx950 (MI355X / CDNA4) LC3plus encode kernels + the C-ABI device shim.
+/* lc3_kernels.hip -- gfx950 (MI355X / CDNA4) LC3plus encode / decode kernels + the C-ABI device shim.
  *
- * One 64-lane wavefront encodes one channel-stream and walks its frames in time order; the spectrum,
- * the 12.8 kHz / 6.4 kHz pitch-analysis histories, the quantised spectrum, the entropy-coder symbol
- * list, all cross-frame scalars and the output frame live in that wave's LDS slice.  PCM is read from HBM
- * with coalesced loads, bytes are written back coalesced; cross-frame state is read once per launch and
- * written once.  No MFMA (nothing here is a dense contraction), no collectives.
+ * This file holds (1) the stage functions of the encoder - one per stage of the reference, each citing its lines - and lc3_encode_kernel, which runs
+ * all of them with ONE CHANNEL-STREAM PER WAVEFRONT, frames in time order, everything in that wave's LDS slice: the path of traced launches, of calls of
+ * a few frames and of the single-stream lc3_enc_* API; (2) the device shim (contexts, launches, streams, events).  The product path for batches is the
+ * PIPELINE of kernels in the lc3_enc_*.inc files included below - resampler, HP50, pitch chain, MDCT front, scale factors, SNS quantiser, shaping + TNS,
+ * rate chain, bitstream writer - each with the unit of work its dependences allow (one frame per lane, four frames per wave, one or two channel-streams
+ * per wave), hand-overs in HBM, three HIP streams, up to three calls in flight.  PCM is read from HBM with coalesced loads, bytes are
+ * written back coalesced.  No MFMA (nothing here is a dense contraction), no collectives.
  *
  * Numerics contract: every floating-point expression keeps the ETSI reference's evaluation order and
  * C promotions (R = LC3plus_ETSI_src_v17171_20200723/src/floating_point, cited per stage), compiled with
@@ -13,7 +15,7 @@
  * which keeps the reference's summation order AND fills the wave.  Strictly serial chains (biquad, normalised
  * correlations, bisection, range coder) run on wave-uniform values: operands are fetched from lane registers
  * with v_readlane (no LDS round trip) and integer state lives in scalar registers.  Run-time libm calls of the
- * reference (log2f, log10f, powf) are evaluated as (float)f((double)x) with the device's double libm.
+ * reference (log2f, log10f, powf(2, .)) are evaluated as (float)f((double)x): lc3_fastmath.h, identical to glibc's double functions for every float argument.
  *
  * Stage functions are deliberately NOT inlined: each gets its own register allocation, which keeps the kernel
  * at <= 3 waves' worth of VGPRs per SIMD instead of the union of all live ranges.
@@ -2907,7 +2909,37 @@ extern "C" __global__ void lc3_enc_rate_kernel_big(const lc3d_plan* __restrict__
 #define LC3D_AHEAD_MAX_FRAMES 256     /* lc3hip_set_input_ready: calls of up to this many frames overlap with their predecessor */
 #define LC3D_RUN_FRAMES 16            /* frames per run when consecutive calls do not overlap (measured, 4096 streams x 64 frames: 8: 58.1, 16: 64.9, 32: 62.8, 64: 58.6 Mframes/s) */
 #define LC3D_RUN_FRAMES_READY 64      /* under the input-ready promise (calls overlap, a call's own pipeline matters less: 8: 62.4, 16: 70.1, 32: 72.6, 64: 73.0) */
+/* The diagnostic switches (LC3PLUS_* environment variables), read ONCE per context in lc3hip_create / lc3hip_dec_create: no function-local statics, so two threads
+ * that drive two batches never race on them, and a context's behaviour does not change under it. */
+struct lc3hip_opts {
+    int fused, no_split, streams5, run_frames, runs, ahead_max, rate_stream /* -1 rule, 0, 1 */, pre_runs, pitch2, scf_wave, front4, shape_fpw, shape_on_s, shape_wave,
+        pack_wpg, pack_stream /* -1 off (default), 0, 1 */, resample48, dec_imdct4, check_ready;
+};
+static int env_int(const char* name, int lo, int hi, int dflt) { const char* e = getenv(name); if (!e || !*e) return dflt; const int v = atoi(e); return v >= lo && v <= hi ? v : dflt; }
+static void read_opts(lc3hip_opts* o)
+{
+    o->fused = env_int("LC3PLUS_ENC_FUSED", 0, 1, 0);                 /* the bitstream writer inside lc3_encode_kernel */
+    o->no_split = env_int("LC3PLUS_ENC_NO_SPLIT", 0, 1, 0);           /* everything in lc3_encode_kernel */
+    o->streams5 = env_int("LC3PLUS_ENC_STREAMS", 0, 8, 0) >= 5;       /* the pitch kernel and the one-frame-per-lane kernels on streams of their own (GPU_MAX_HW_QUEUES >= 6) */
+    o->run_frames = env_int("LC3PLUS_ENC_RUN_FRAMES", 1, 1 << 20, 0);
+    o->runs = env_int("LC3PLUS_ENC_RUNS", 1, 16, 0);
+    o->ahead_max = env_int("LC3PLUS_ENC_AHEAD_MAX", 1, 1 << 20, 0);
+    o->rate_stream = env_int("LC3PLUS_ENC_RATE_STREAM", 0, 1, -1);
+    o->pre_runs = env_int("LC3PLUS_ENC_PRE_RUNS", 1, 64, 3);
+    o->pitch2 = env_int("LC3PLUS_ENC_PITCH2", 0, 1, 1);              /* 0 = one stream per wave */
+    o->scf_wave = env_int("LC3PLUS_ENC_SCF_WAVE", 0, 1, 0);          /* energies / scale factors in the front kernel */
+    o->front4 = env_int("LC3PLUS_ENC_FRONT4", 0, 1, 1);              /* 0 = the one-frame-at-a-time front for every frame length */
+    o->shape_fpw = env_int("LC3PLUS_ENC_SHAPE_FPW", 1, 64, 0);
+    o->shape_on_s = env_int("LC3PLUS_ENC_SHAPE_ON_S", 0, 1, 0);
+    o->shape_wave = env_int("LC3PLUS_ENC_SHAPE_WAVE", 0, 1, 0);      /* the wave-per-frame shape kernel */
+    o->pack_wpg = env_int("LC3PLUS_ENC_PACK_WPG", 1, 4, 4);          /* waves per workgroup of the writer */
+    o->pack_stream = env_int("LC3PLUS_ENC_PACK_STREAM", 0, 1, -1);   /* 1 = the writers of consecutive calls on two side streams (deployment switch, see enc_launch) */
+    o->resample48 = env_int("LC3PLUS_ENC_RESAMPLE48", 0, 1, 1);      /* 0 = the two-outputs-per-lane resampler for 48 kHz / 10 ms too */
+    o->check_ready = env_int("LC3PLUS_CHECK_READY", 0, 1, 0);        /* debug aid for lc3plus_enc_batch_set_input_ready: refuse a call made while foreign work is pending on the caller's stream */
+    o->dec_imdct4 = env_int("LC3PLUS_DEC_IMDCT4", 0, 1, 1);          /* 0 = the one-frame-at-a-time IMDCT for N = 480 too */
+}
 struct lc3hip_ctx {
+    lc3hip_opts opt;
     int device, ncs, n_streams, channels, N, big, state_words, rs48;
     lc3d_plan* d_plan; lc3d_chan* d_chans; float* d_state;
     void* d_pcm; size_t pcm_cap; uint8_t* d_out; size_t out_cap;
@@ -2923,6 +2955,7 @@ struct lc3hip_ctx {
     hipStream_t s_pre, s_fr, s_pit, s_ln, s_rt; hipEvent_t ev_rate; int rate_armed, mean_nbytes; int* h_nb; hipEvent_t ev_fork, ev_p[LC3D_MAX_RUNS], ev_f[LC3D_MAX_RUNS], ev_h[LC3D_MAX_RUNS], ev_m[LC3D_MAX_RUNS];   /* side streams: pitch chain, frame-parallel front, frame-parallel tail */
     int ylen, srow, la, len12, fm_frames; const float* last_frec; int last_frec_frames;      /* the records of the last pipelined call (lc3hip_last_records) */
     hipStream_t stream, last_stream; hipEvent_t ev0, ev1; float last_ms;
+    hipEvent_t ev_ours, ev_now; int ours_armed;       /* LC3PLUS_CHECK_READY: the tail of the library's own work on the caller's stream */
 };
 
 #define LC3D_FUSED_MAX_T 8
@@ -2948,8 +2981,9 @@ extern "C" int lc3hip_create(void** out_ctx, const lc3d_plan* plan, int n_stream
     c->fm_frames = (!c->big && plan->pfa_nst >= 2 && plan->pfa_rad[0] <= 8 && plan->pfa_rad[1] <= 8 && (plan->pfa_nst < 3 || plan->pfa_rad[2] <= 8) && plan->N <= 240) ? (plan->N > 120 ? 4 : 8) : 0;      /* lc3_enc_frontm_kernel */
     c->srow = LC3D_SROW(plan->ylen);
     c->rs48 = plan->N == 480 && plan->rs_stride == 4 && plan->n12 == 128 && plan->rs_mem_in_len == 60;      /* lc3_enc_resample48_kernel */
-    { const char* e = getenv("LC3PLUS_ENC_RESAMPLE48"); if (e && e[0] == '0') c->rs48 = 0; }     /* diagnostic: the two-outputs-per-lane kernel */
-    { const char* e = getenv("LC3PLUS_ENC_FUSED"); c->fused = e && e[0] == '1'; }     /* diagnostic: the bitstream writer inside lc3_encode_kernel */
+    read_opts(&c->opt);
+    if (!c->opt.resample48) c->rs48 = 0;
+    c->fused = c->opt.fused;
     c->state_words = LC3D_STATE_WORDS(c->big ? LC3D_MEMCAP_BIG : LC3D_MEMCAP_STD);
     HIPCHK_OR(hipMalloc((void**)&c->d_plan, sizeof(lc3d_plan)), lc3hip_destroy(c));
     HIPCHK_OR(hipMemcpy(c->d_plan, plan, sizeof(lc3d_plan), hipMemcpyHostToDevice), lc3hip_destroy(c));
@@ -3047,9 +3081,7 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
         if (c->y12_cap[yb] < need) { if (c->d_y12[yb]) HIPCHK(hipFree(c->d_y12[yb])); c->d_y12[yb] = nullptr; c->y12_cap[yb] = 0; HIPCHK(hipMalloc((void**)&c->d_y12[yb], need * sizeof(float))); c->y12_cap[yb] = need; }
         dy12 = c->d_y12[yb];
     }
-    static int split_off = -1;
-    if (split_off < 0) { const char* e = getenv("LC3PLUS_ENC_NO_SPLIT"); split_off = e && e[0] == '1'; }
-    const bool split = dy12 && ddump && !split_off;
+    const bool split = dy12 && ddump && !c->opt.no_split;
     if (dt0 == 0) {   /* per channel-frame status bits (LC3D_ENC_ST_*), cleared per call: by the stream that runs the kernel that sets them (the writer's, on the pipelined path) */
         const size_t need = (size_t)c->ncs * dT;
         if (c->status_capv[set] < need) { if (c->d_statusv[set]) HIPCHK(hipFree(c->d_statusv[set])); c->d_statusv[set] = nullptr; c->status_capv[set] = 0; HIPCHK(hipMalloc((void**)&c->d_statusv[set], need)); c->status_capv[set] = need; }
@@ -3091,10 +3123,10 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
             HIPCHK(hipStreamCreateWithFlags(&c->s_pre, hipStreamNonBlocking)); HIPCHK(hipStreamCreateWithFlags(&c->s_fr, hipStreamNonBlocking));
             /* LC3PLUS_ENC_STREAMS=5: the pitch kernel and the one-frame-per-lane kernels on streams of their own (pays only where the HIP runtime has
              * hardware queues for them: GPU_MAX_HW_QUEUES >= 6) */
-            { const char* e = getenv("LC3PLUS_ENC_STREAMS"); c->s_pit = c->s_pre; c->s_ln = c->s_fr;
-              if (e && atoi(e) >= 5) { HIPCHK(hipStreamCreateWithFlags(&c->s_pit, hipStreamNonBlocking)); HIPCHK(hipStreamCreateWithFlags(&c->s_ln, hipStreamNonBlocking)); } }
+            { c->s_pit = c->s_pre; c->s_ln = c->s_fr;
+              if (c->opt.streams5) { HIPCHK(hipStreamCreateWithFlags(&c->s_pit, hipStreamNonBlocking)); HIPCHK(hipStreamCreateWithFlags(&c->s_ln, hipStreamNonBlocking)); } }
             for (int i = 0; i < LC3D_MAX_RUNS; i++) { HIPCHK(hipEventCreateWithFlags(&c->ev_h[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_m[i], hipEventDisableTiming)); }
-            c->s_rt = NULL;
+            HIPCHK(hipStreamCreateWithFlags(&c->s_rt, hipStreamNonBlocking));      /* with the others: no stream creation inside a later (timed) call */
             for (int i = 0; i < 2; i++) { c->s_pk[i] = NULL; HIPCHK(hipEventCreateWithFlags(&c->ev_pk[i], hipEventDisableTiming)); }
             HIPCHK(hipEventCreateWithFlags(&c->ev_rate, hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -3104,13 +3136,11 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
         float* dspec = c->d_spec[hb_]; float* dfrec = c->d_frec[hb_];
         rows_for_pack = dspec; frec_for_pack = dfrec;
         c->last_frec = dfrec; c->last_frec_frames = dT;
-        static int runf_env = -1;
-        if (runf_env < 0) { const char* e = getenv("LC3PLUS_ENC_RUN_FRAMES"); runf_env = e && atoi(e) >= 1 ? atoi(e) : 0; }     /* diagnostic */
-        const int runf = runf_env ? runf_env : c->input_ready ? LC3D_RUN_FRAMES_READY : LC3D_RUN_FRAMES;
+        const int runf = c->opt.run_frames ? c->opt.run_frames : c->input_ready ? LC3D_RUN_FRAMES_READY : LC3D_RUN_FRAMES;
         int R = (n_frames + runf - 1) / runf;              /* runs of frames */
         if (R > LC3D_MAX_RUNS) R = LC3D_MAX_RUNS;
         if (R < 1) R = 1;
-        { const char* e = getenv("LC3PLUS_ENC_RUNS"); if (e && atoi(e) >= 1 && atoi(e) <= LC3D_MAX_RUNS) R = atoi(e); }     /* diagnostic */
+        if (c->opt.runs) R = c->opt.runs;
         const int Tr = (n_frames + R - 1) / R;
         /* Where the side kernels of this call may start.  Normally behind everything the caller queued on s before the call (the PCM may
          * come from there).  With lc3hip_set_input_ready - the PCM of a call is complete when the call is made - and a previous call of
@@ -3118,8 +3148,7 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
          * their own order, writing the other set of rows and records (the set they write now was last read by the writer of the call before
          * the previous one: ev_done); the MDCT memory before frame 0 is read from the previous call's hand-over (two alternating buffers),
          * not from the state that call's last rate kernel is still to update. */
-        static int amax = 0;
-        if (!amax) { const char* e = getenv("LC3PLUS_ENC_AHEAD_MAX"); amax = e && atoi(e) >= 1 ? atoi(e) : LC3D_AHEAD_MAX_FRAMES; }     /* diagnostic */
+        const int amax = c->opt.ahead_max ? c->opt.ahead_max : LC3D_AHEAD_MAX_FRAMES;
         const bool ahead = c->input_ready && n_frames <= amax && c->ahead_ok && c->ahead_T == n_frames && c->ahead_R == R && c->last_stream == s && dt0 == 0 && dT == n_frames && pack;
         float* xn_w = c->d_xnext[c->xn_par];                         /* written by this call's front kernel */
         /* one buffer more than calls in flight: the one written now was last read by the call LC3D_SETS back (its resampler and front) and by the
@@ -3132,10 +3161,8 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
          * large frames (the writer's work grows with the bytes: c96 22 -> 32 Mframes/s, c5 77 -> 83) and short calls (c3 +3 %); on 80-byte frames in
          * calls of 64 (c1) a fourth side stream costs 0 ... 11 % (it shares one of HIP's four hardware queues with another, depending on what else the
          * process created), and on c4 4 %.  LC3PLUS_ENC_RATE_STREAM=0 / 1 forces the choice (diagnostic). */
-        static int rt_env = -2;
-        if (rt_env == -2) { const char* e = getenv("LC3PLUS_ENC_RATE_STREAM"); rt_env = !e ? -1 : e[0] == '1' ? 1 : e[0] == '0' ? 0 : -1; }
+        const int rt_env = c->opt.rate_stream;
         const bool want_rt = rt_env == 1 || (rt_env < 0 && (c->mean_nbytes >= 120 || n_frames <= 32));
-        if (want_rt && !c->s_rt) HIPCHK(hipStreamCreateWithFlags(&c->s_rt, hipStreamNonBlocking));
         hipStream_t rts = want_rt ? c->s_rt : NULL;          /* NULL: the rate kernels run on the caller's stream */
         if (!ahead) {
             HIPCHK(hipEventRecord(c->ev_fork, s)); HIPCHK(hipStreamWaitEvent(c->s_pre, c->ev_fork, 0)); HIPCHK(hipStreamWaitEvent(c->s_fr, c->ev_fork, 0));
@@ -3158,8 +3185,7 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
         for (int k = 0, tb = 0, hb = 0, hk = 0; tb < n_frames; k++, tb += Tr) {
             const int nt = n_frames - tb < Tr ? n_frames - tb : Tr;
             if (tb >= hb) {
-                static int prn = 0;
-                if (!prn) { const char* e = getenv("LC3PLUS_ENC_PRE_RUNS"); prn = e && atoi(e) >= 1 ? atoi(e) : 3; }     /* diagnostic */
+                const int prn = c->opt.pre_runs;
                 const int hn0 = hk == 0 ? Tr : prn * Tr, hn = n_frames - hb < hn0 ? n_frames - hb : hn0;
                 DUPL('r') launch_resample(c, c->s_pre, dpcm, bitdepth, n_frames, hb, hn, mc, dy12, xprev, xprev_stride);
                 DUPL('h') hipLaunchKernelGGL(lc3_enc_hp50_kernel, dim3((unsigned)((c->ncs + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->s_pre, c->d_plan, c->d_state, c->state_words, LC3D_ST_SCAL(mc), n_frames, hb, hn, c->ncs, dy12);
@@ -3167,8 +3193,7 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
                 hb += hn; hk++;
                 if (five) { HIPCHK(hipEventRecord(c->ev_h[k], c->s_pre)); HIPCHK(hipStreamWaitEvent(c->s_pit, c->ev_h[k], 0)); }
             }
-            static int p2 = -1;
-            if (p2 < 0) { const char* e = getenv("LC3PLUS_ENC_PITCH2"); p2 = !(e && e[0] == '0'); }     /* diagnostic: 0 = one stream per wave */
+            const int p2 = c->opt.pitch2;
             if (p2 && (c->len12 == 128 || c->len12 == 64 || c->len12 == 32)) {
                 auto pk = c->len12 == 128 ? lc3_enc_pitch2_kernel : c->len12 == 64 ? lc3_enc_pitch2_kernel_l64 : lc3_enc_pitch2_kernel_l32;
                 DUPL('p') hipLaunchKernelGGL(pk, dim3((unsigned)((c->ncs + 1) / 2)), dim3(WAVE), 0, c->s_pit, c->d_plan, c->d_chans, c->d_state, c->state_words, mc, dy12, n_frames, tb, nt, c->ncs, dfrec, dT, dt0);
@@ -3176,12 +3201,10 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
             else DUPL('p') hipLaunchKernelGGL(lc3_enc_pitch_kernel, dim3(c->ncs), dim3(WAVE), 0, c->s_pit, c->d_plan, c->d_chans, c->d_state, c->state_words, mc, dy12, n_frames, tb, nt, c->ncs, dfrec, dT, dt0);
             HIPCHK(hipGetLastError());
             HIPCHK(hipEventRecord(c->ev_p[k], c->s_pit));
-            static int scf_wave = -1;
-            if (scf_wave < 0) { const char* e = getenv("LC3PLUS_ENC_SCF_WAVE"); scf_wave = e && e[0] == '1'; }     /* diagnostic: energies / scale factors in the front kernel */
+            const int scf_wave = c->opt.scf_wave;
             const int fpw = nt < FRONT_FPW ? nt : FRONT_FPW;
             const unsigned fruns = (unsigned)((nt + fpw - 1) / fpw);
-            static int f4 = -1;
-            if (f4 < 0) { const char* e = getenv("LC3PLUS_ENC_FRONT4"); f4 = !(e && e[0] == '0'); }     /* diagnostic: 0 = the one-frame-at-a-time kernel for N = 480 too */
+            const int f4 = c->opt.front4;
             if (f4 && !c->big && !scf_wave && c->N == 480 && c->la == 180 && (c->ylen & 15) == 0)
                 DUPL('f') hipLaunchKernelGGL(lc3_enc_front4_kernel, dim3((unsigned)c->ncs * (unsigned)((nt + 3) / 4)), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames, tb, nt, c->ncs, dspec, c->srow, dT, dt0, dfrec, xn_w, xprev, xprev_stride);
             else if (f4 && c->fm_frames && !scf_wave)
@@ -3197,16 +3220,13 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
             DUPL('v') hipLaunchKernelGGL(lc3_enc_snsvq_kernel, dim3((unsigned)((nfr + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->s_ln, c->d_plan, dfrec, dT, dt0, tb, nt, c->ncs, c->any_attack);
             {   /* shaping, TNS and the stateless half of the gain estimate: frame-parallel, behind the quantiser (LC3PLUS_ENC_SHAPE_ON_S=1, diagnostic: on the
                  * launch stream in front of the rate kernel instead) */
-                static int sfpw = 0, son = -1;
-                if (!sfpw) { const char* e = getenv("LC3PLUS_ENC_SHAPE_FPW"); sfpw = e && atoi(e) >= 1 ? atoi(e) : SHAPE_FPW; }     /* diagnostic */
-                if (son < 0) { const char* e = getenv("LC3PLUS_ENC_SHAPE_ON_S"); son = e && e[0] == '1'; }
+                const int sfpw = c->opt.shape_fpw ? c->opt.shape_fpw : SHAPE_FPW, son = c->opt.shape_on_s;
                 const int spw = nt < sfpw ? nt : sfpw;
                 const unsigned sruns = (unsigned)((nt + spw - 1) / spw);
                 hipStream_t ss = son ? s : c->s_ln;
                 rs = (son || !rts) ? s : rts;
                 if (son) { HIPCHK(hipEventRecord(c->ev_f[k], c->s_ln)); HIPCHK(hipStreamWaitEvent(s, c->ev_f[k], 0)); }
-                static int swave = -1;
-                if (swave < 0) { const char* e = getenv("LC3PLUS_ENC_SHAPE_WAVE"); swave = e && e[0] == '1'; }     /* diagnostic: the wave-per-frame kernel */
+                const int swave = c->opt.shape_wave;
                 if (!swave) DUPL('a') hipLaunchKernelGGL(lc3_enc_shape_lane_kernel, dim3((unsigned)(((long long)c->ncs * nt + WAVE - 1) / WAVE)), dim3(WAVE), 0, ss, c->d_plan, c->d_chans, dT, dt0 + tb, nt, c->ncs, dspec, c->srow, dfrec);
                 else if (c->big) hipLaunchKernelGGL(lc3_enc_shape_kernel_big, dim3((unsigned)c->ncs * sruns), dim3(WAVE), 0, ss, c->d_plan, c->d_chans, dT, dt0 + tb, nt, spw, c->ncs, dspec, c->srow, dfrec);
                 else DUPL('a') hipLaunchKernelGGL(lc3_enc_shape_kernel, dim3((unsigned)c->ncs * sruns), dim3(WAVE), 0, ss, c->d_plan, c->d_chans, dT, dt0 + tb, nt, spw, c->ncs, dspec, c->srow, dfrec);
@@ -3226,8 +3246,7 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
     }
     if (ddump && pack) {
         HIPCHK(hipGetLastError());
-        static int wpg = 0;                               /* waves per workgroup of the writer (they share the coder's tables in LDS) */
-        if (!wpg) { const char* e = getenv("LC3PLUS_ENC_PACK_WPG"); wpg = e && atoi(e) >= 1 && atoi(e) <= 4 ? atoi(e) : 4; }     /* diagnostic */
+        const int wpg = c->opt.pack_wpg;                  /* waves per workgroup of the writer (they share the coder's tables in LDS) */
         const size_t per_wave = (size_t)PK_XBUF * WAVE * sizeof(unsigned);
         const long long tasks = (long long)c->ncs * dT, per_wg = (long long)wpg * WAVE;
         /* The writer codes one frame per lane: its duration is the latency of the LARGEST frame of the batch (c5: 1.7 ms for 400 bytes, c96: 3.2 ms), whatever the
@@ -3237,8 +3256,7 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
          * off / on): with HIP's default four hardware queues c5 87.0 / 80.0, c96 32.1 / 28.7, c3 85.1 / 73.0 - six streams share four queues and kernels of two
          * streams on one queue run back to back; with GPU_MAX_HW_QUEUES=8 c5 90.9 / 92.4, c96 28.8 / 33.9, c3 85.5 / 85.8.  So it is a deployment switch
          * (LC3PLUS_ENC_PACK_STREAM=1 together with GPU_MAX_HW_QUEUES >= 6), off by default. */
-        static int pk_env = -2;
-        if (pk_env == -2) { const char* e = getenv("LC3PLUS_ENC_PACK_STREAM"); pk_env = !e ? -1 : e[0] == '1' ? 1 : e[0] == '0' ? 0 : -1; }     /* diagnostic */
+        const int pk_env = c->opt.pack_stream;
         const bool side = split && rate_on_side && c->input_ready && dt0 == 0 && dT == n_frames && pk_env == 1;
         hipStream_t ps = s;
         if (side) {
@@ -3349,9 +3367,22 @@ extern "C" int lc3hip_encode(void* ctx, const void* pcm, int pcm_on_device, int 
         HIPCHK(hipMemsetAsync(c->d_trace, 0, tb, s));
         dtr = c->d_trace;
     }
+    if (c->opt.check_ready && c->input_ready && pcm_on_device) {
+        /* The promise says the PCM is complete NOW.  What can be checked: if everything this library queued on s has finished and s still has work pending, that work is
+         * the caller's - possibly the producer of this PCM.  (While our own work is pending nothing can be told apart; the check is a debug aid, not a proof.) */
+        if (!c->ev_ours) { HIPCHK(hipEventCreateWithFlags(&c->ev_ours, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_now, hipEventDisableTiming)); }
+        if ((!c->ours_armed || c->last_stream != s || hipEventQuery(c->ev_ours) == hipSuccess) && hipStreamQuery(s) == hipErrorNotReady) {
+            fprintf(stderr, "lc3plus_hip: LC3PLUS_CHECK_READY: lc3plus_enc_batch_set_input_ready(1) is in force, but work queued by the caller is still pending on the stream "
+                            "of this call - the PCM (or the output buffer) may not be ready; call refused\n");
+            (void)hipGetLastError();
+            return 1;
+        }
+        (void)hipGetLastError();
+    }
     HIPCHK(hipEventRecord(c->ev0, s));
     if (enc_launch(c, dpcm, bitdepth, n_frames, dout, out_stride, s, dtr, n_frames, 0, true)) return 1;
     HIPCHK(hipEventRecord(c->ev1, s));
+    if (c->opt.check_ready && c->ev_ours) { HIPCHK(hipEventRecord(c->ev_ours, s)); c->ours_armed = 1; }
     if (!out_on_device) HIPCHK(hipMemcpyAsync(out, dout, out_bytes, hipMemcpyDeviceToHost, s));
     if (trace_host) HIPCHK(hipMemcpyAsync(trace_host, dtr, sizeof(lc3d_trace) * (size_t)c->ncs * n_frames, hipMemcpyDeviceToHost, s));
     if (sync || !out_on_device || trace_host) {
@@ -3454,6 +3485,7 @@ extern "C" int lc3hip_destroy(void* ctx)
                     for (int i = 0; i < LC3D_MAX_RUNS; i++) { hipEventDestroy(c->ev_p[i]); hipEventDestroy(c->ev_f[i]); } }
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->ev_ours) { hipEventDestroy(c->ev_ours); hipEventDestroy(c->ev_now); }
     if (c->stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); }
     free(c);
     return 0;
@@ -3465,6 +3497,7 @@ extern "C" __global__ void lc3_dec_synth_kernel_big(const lc3d_plan* __restrict_
                                                     const float* __restrict__ ws, const float* __restrict__ ov, int T, void* __restrict__ pcm, int bps, int ncs,
                                                     uint8_t* __restrict__ status, lc3d_dec_trace* __restrict__ trace);
 struct lc3hip_dctx {
+    lc3hip_opts opt;
     int device, ncs, n_streams, channels, N, big;
     lc3d_plan* d_plan; lc3d_dchan* d_chans; float* d_state;
     uint8_t* d_in; size_t in_cap; void* d_pcm; size_t pcm_cap; uint8_t* d_bfi; size_t bfi_cap;
@@ -3488,6 +3521,7 @@ extern "C" int lc3hip_dec_create(void** out_ctx, const lc3d_plan* plan, int n_st
     HIPCHK_OR(hipSetDevice(device), free(c));
     c->n_streams = n_streams; c->channels = plan->channels; c->ncs = n_streams * plan->channels; c->N = plan->N;
     c->big = LC3D_LAYOUT_BIG(plan->N, plan->la);
+    read_opts(&c->opt);
     HIPCHK_OR(hipMalloc((void**)&c->d_plan, sizeof(lc3d_plan)), lc3hip_dec_destroy(c));
     HIPCHK_OR(hipMemcpy(c->d_plan, plan, sizeof(lc3d_plan), hipMemcpyHostToDevice), lc3hip_dec_destroy(c));
     HIPCHK_OR(hipMalloc((void**)&c->d_chans, sizeof(lc3d_dchan) * c->ncs), lc3hip_dec_destroy(c));
@@ -3618,8 +3652,7 @@ extern "C" int lc3hip_dec_decode(void* ctx, const void* frames, int frames_on_de
         hipLaunchKernelGGL(lc3_dec_imdct_kernel_big, dim3(ncf), dim3(WAVE), 0, s, c->d_plan, c->d_state, rec_w, ws_w, n_frames, c->ncs, c->d_ov, dtr);
         hipLaunchKernelGGL(lc3_dec_synth_kernel_big, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, rec_w, ws_w, c->d_ov, n_frames, dpcm, bps, c->ncs, dst, dtr);
     } else {
-        static int i4 = -1;
-        if (i4 < 0) { const char* e = getenv("LC3PLUS_DEC_IMDCT4"); i4 = !(e && e[0] == '0'); }     /* diagnostic: 0 = the one-frame-at-a-time kernel for N = 480 too */
+        const int i4 = c->opt.dec_imdct4;
         if (i4 && !dtr && c->N == 480)
             hipLaunchKernelGGL(lc3_dec_imdct4_kernel, dim3((unsigned)((size_t)c->ncs * ((n_frames + 3) / 4))), dim3(WAVE), 0, s, c->d_plan, c->d_state, rec_w, ws_w, n_frames, c->ncs, c->d_ov);
         else

@@ -44,8 +44,8 @@ int   lc3hip_dec_get_state(void* ctx, void* host, size_t bytes);
 int   lc3hip_dec_set_state(void* ctx, const void* host, size_t bytes);
 int   lc3hip_dec_set_input_ready(void* ctx, int ready);          /* see lc3plus_dec_batch_set_input_ready (include/lc3plus_batch.h) */
 int   lc3hip_set_input_ready(void* ctx, int ready);              /* see lc3plus_enc_batch_set_input_ready (include/lc3plus_batch.h) */
-int   lc3hip_last_status(void* ctx, uint8_t* status_host, int n);
-int   lc3hip_last_records(void* ctx, float* rec_host, int max_words);   /* the per-frame records of the last pipelined call [channel-stream][frame][FR_WORDS]; returns the words copied */   /* LC3D_ENC_ST_* bits per channel-frame of the last call; returns the count copied */
+int   lc3hip_last_status(void* ctx, uint8_t* status_host, int n);        /* LC3D_ENC_ST_* bits per channel-frame of the last call; returns the count copied */
+int   lc3hip_last_records(void* ctx, float* rec_host, int max_words);   /* the per-frame records of the last pipelined call [channel-stream][frame][FR_WORDS]; returns the words copied (0: the last call did not take that path) */
 int   lc3hip_destroy(void* ctx);
 #ifdef __cplusplus
 }

@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 RATES12 = [16000, 24000, 32000, 48000, 64000, 80000, 96000, 128000, 160000, 192000, 256000, 320000]
 # name: (fs, frame_ms, hrmode, channels, N, per-stream total bitrates (cycled), frames per step, streams per GPU, what)
 WORKLOADS = {
-    "c1": (48000, 10.0, 0, 1, 480, [64000], 64, 4096, "BASELINE configs[1]: independent mono streams, 48kHz/10ms/64kbps, one channel-stream per wavefront"),
+    "c1": (48000, 10.0, 0, 1, 480, [64000], 64, 4096, "BASELINE configs[1]: independent mono streams, 48kHz/10ms/64kbps (pipelined kernels: one frame per lane / four frames per wave / one or two channel-streams per wave)"),
     # configs[2]: 262 144 stereo frames over 8 GPUs = 16 384 stereo streams x 16 frames -> 2 048 stereo streams per GPU
     "c3": (48000, 10.0, 0, 2, 480, [128000], 16, 2048, "BASELINE configs[2]: stereo streams, 48kHz/10ms/128kbps (80 B per channel); 8 GPUs x 2048 streams x 16 frames = 262144 stereo frames"),
     "c4": (96000, 2.5, 1, 1, 240, [256000], 256, 4096, "BASELINE configs[3]: 96kHz/2.5ms high-resolution 256kbps mono"),
@@ -69,6 +69,7 @@ def timed_steps(step, steps, warmup, sync, dist=None, device=None):
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
+    timed_steps.enqueue = time.perf_counter() - t0        # host time to queue the K steps (the GPU runs behind it)
     sync()
     if dist is not None: dist.barrier()
     sync()
@@ -79,6 +80,21 @@ def timed_steps(step, steps, warmup, sync, dist=None, device=None):
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall = float(tw.item())
     return wall
+
+
+def rank_plan(workload, rank, world, streams=0, frames=0):
+    """What one rank of an N-rank run works on (weak scaling: every rank owns B of the B x N streams of the job, a contiguous block; no exchange step):
+    the block, its per-stream bitrates (cycled over the GLOBAL stream index) and the seed of its synthetic PCM.  main() and tests/test_sharding_gloo.py
+    (two gloo ranks, the oracle as the step) both run from this."""
+    from audio_codec_amd.sharding import stream_block
+    fs, ms, hr, ch, n, rates, T, B, what = WORKLOADS[workload]
+    if frames: T = frames
+    if streams: B = streams
+    first, last = stream_block(rank, world, B * world)
+    assert last - first == B
+    return {"fs": fs, "ms": ms, "hr": hr, "ch": ch, "n": n, "T": T, "B": B, "what": what, "first": first, "last": last,
+            "br": [rates[(first + i) % len(rates)] for i in range(B)], "seed": 1234 + first,
+            "job_streams": B * world, "job_channel_frames_per_step": B * world * T * ch}
 
 
 def rank_env():
@@ -144,6 +160,52 @@ def parity_sample(pcm, out, nbl, br, fs, ms, hr, ch, calls, sample):
     return {"frames": frames, "differ": differ, "streams": len(sample),
             "note": "oracle/liblc3_oracle_pm.so over all %d calls of the run on the sampled streams (state runs on), the last call's frames compared with "
                     "the timed launches' output buffer byte for byte" % calls}
+
+
+def parity_sample_dec(frames, back, nbl, fs, ms, hr, ch, calls, sample):
+    """The decoder's timed launches against the CPU oracle decoder (checker only): `sample` streams, every call of the run decoded in order (the
+    decoder's state runs on from call to call over the same frames), the last call's PCM compared sample for sample."""
+    import ctypes as C
+    import numpy as np
+    L = C.CDLL(os.path.join(ROOT, "oracle", "liblc3_oracle_pm.so"))
+    L.lc3o_dec_set_frame_ms.argtypes = [C.c_void_p, C.c_float]
+    L.lc3o_dec_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_int, C.c_int]
+    T = frames.shape[1]
+    n = differ = 0
+    for i in sample:
+        buf = C.create_string_buffer(L.lc3o_dec_sizeof() + 8); h = C.cast(buf, C.c_void_p)
+        if L.lc3o_dec_init(h, fs, ch) or L.lc3o_dec_set_frame_ms(h, ms) or L.lc3o_dec_set_hrmode(h, hr): raise RuntimeError("oracle decoder setup")
+        N = L.lc3o_dec_get_output_samples(h)
+        fr = np.ascontiguousarray(frames[i, :, :nbl[i]].cpu().numpy())
+        got = back[i].cpu().numpy()                                          # [T, ch, N]
+        o = np.zeros((ch, N), np.int16)
+        ptrs = (C.c_void_p * ch)(*[o[c].ctypes.data for c in range(ch)])
+        for k in range(calls):
+            for t in range(T):
+                rc = L.lc3o_dec_frame(h, fr[t].ctypes.data, int(nbl[i]), ptrs, 16, 0)
+                if rc not in (0, 2): raise RuntimeError("oracle decoder rc %d" % rc)
+                if k == calls - 1:
+                    n += ch; differ += int((got[t] != o).any(axis=1).sum())
+    return {"frames": n, "differ": differ, "streams": len(sample),
+            "note": "oracle/liblc3_oracle_pm.so's decoder over all %d calls of the run on the sampled streams (state runs on), the last call's PCM compared with "
+                    "the timed launches' output buffer sample for sample" % calls}
+
+
+def gpu_numa_cpus(local):
+    """The CPUs of the NUMA node the local_rank-th AMD GPU hangs off (sysfs only: nothing here touches the GPU), or None.  Devices in PCI address order,
+    which is HIP's enumeration order unless HIP_VISIBLE_DEVICES reorders them (then: None)."""
+    import glob
+    if os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES") or os.environ.get("CUDA_VISIBLE_DEVICES"): return None
+    try:
+        devs = sorted(d for d in glob.glob("/sys/bus/pci/drivers/amdgpu/0000:*") if os.path.exists(os.path.join(d, "numa_node")))
+        node = int(open(os.path.join(devs[local], "numa_node")).read())
+        if node < 0: return None
+        cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            a, _, b = part.partition("-"); cpus.update(range(int(a), int(b or a) + 1))
+        return node, sorted(cpus)
+    except (OSError, ValueError, IndexError):
+        return None
 
 
 def cpu_baseline(kind_dir, mode, fs, ms, hr, ch, rate_or_nbytes, sample, S, T, tag):
@@ -246,6 +308,11 @@ def main():
         print("bench.py: --gpus %d but WORLD_SIZE=%d" % (a.gpus, world), file=sys.stderr)
         sys.exit(3)
 
+    # this rank's threads (and with them the pinned staging buffers they allocate: first touch) on the NUMA node of its GPU, before anything touches the GPU
+    numa = gpu_numa_cpus(local) if world > 1 or os.environ.get("LC3_BENCH_NUMA") == "1" else None
+    if numa:
+        try: os.sched_setaffinity(0, set(numa[1]) & os.sched_getaffinity(0) or os.sched_getaffinity(0))
+        except OSError: numa = None
     import torch
     import audio_codec_amd
     if torch.cuda.device_count() <= local:
@@ -259,15 +326,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    fs, ms, hr, ch, n, rates, T, B, what = WORKLOADS[a.workload]
-    if a.frames: T = a.frames
-    if a.streams: B = a.streams
+    plan = rank_plan(a.workload, rank, world, a.streams, a.frames)          # weak scaling: every rank owns B of the B*world streams
+    fs, ms, hr, ch, n, T, B, what, first, br = (plan[k] for k in ("fs", "ms", "hr", "ch", "n", "T", "B", "what", "first", "br"))
     decode = a.workload.startswith("d")
-    from audio_codec_amd.sharding import stream_block
-    first, last = stream_block(rank, world, B * world)          # weak scaling: every rank owns B of the B*world streams
-    assert last - first == B
-    pcm = synth_pcm_device(torch, B, T, ch, n, fs, dev, seed=1234 + first, first_stream=first)
-    br = [rates[(first + i) % len(rates)] for i in range(B)]
+    pcm = synth_pcm_device(torch, B, T, ch, n, fs, dev, seed=plan["seed"], first_stream=first)
     batch = audio_codec_amd.Batch(B, fs, ch, ms, hr, br, device=local)
     stride = batch.stride
     out = torch.zeros(B, T, stride, dtype=torch.uint8, device=dev)
@@ -308,11 +370,20 @@ def main():
                 par = parity_sample(pcm, out, nbl, br, fs, ms, hr, ch, a.warmup + a.steps, smp)
             except Exception as ex:
                 par = {"frames": 0, "differ": None, "note": "failed: %r" % (ex,)}
+    enqueue_ms = timed_steps.enqueue / a.steps * 1e3
+    if decode and rank == 0 and not a.no_parity:
+        try:
+            smp = sorted({i for i in (0, 1, 5, 21, 62, 63, B - 1) if 0 <= i < B})
+            par = parity_sample_dec(out, back, nbl, fs, ms, hr, ch, a.warmup + a.steps, smp)
+        except Exception as ex:
+            par = {"frames": 0, "differ": None, "note": "failed: %r" % (ex,)}
     per_rank_ms = [round(wall_local / a.steps * 1e3, 4)]
+    per_rank_kernel_ms = [round(kern_ms, 4)]
     if dist is not None:
-        tw = torch.zeros(world, dtype=torch.float64, device=dev); tw[rank] = wall_local
+        tw = torch.zeros(2, world, dtype=torch.float64, device=dev); tw[0, rank] = wall_local; tw[1, rank] = kern_ms
         dist.all_reduce(tw)
-        per_rank_ms = [round(float(v) / a.steps * 1e3, 4) for v in tw.tolist()]
+        per_rank_ms = [round(float(v) / a.steps * 1e3, 4) for v in tw[0].tolist()]
+        per_rank_kernel_ms = [round(float(v), 4) for v in tw[1].tolist()]
 
     if rank == 0:
         units = B * T * ch                                   # channel-frames per step per GPU
@@ -333,16 +404,23 @@ def main():
                        "streams_per_gpu": B, "frames_per_step": T, "channels": ch, "bytes_per_frame": sorted(set(nbl)),
                        "stereo_frames_per_step_all_gpus": B * T * world if ch == 2 else None,
                        "parallelism": "streams sharded over %d GPU(s) by contiguous blocks, no collectives" % world,
-                       "input_ready": (not decode and not a.serial_calls),
+                       "input_ready": not a.serial_calls,
+                       "numa": {"node": numa[0], "cpus": len(numa[1])} if numa else None,
                        "pcm": "synthetic, SURVEY 8(d) recipe as tests/lc3_harness.py states it (3 sinusoids + coloured noise + 20 dB transients at -20 dB; "
                               "1/4 of the streams strongly periodic, 1/64 digital silence, 1/64 full-scale white noise)"},
             "per_rank_ms": per_rank_ms,
+            "host_enqueue_ms_per_step": round(enqueue_ms, 4),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None if prof.get("stale") else prof.get("traffic_bytes"),
                          "kernel": kernels + " (one call = these launches; HIP events on the launch stream around all of them)",
                          "kernel_ms_avg": round(kern_ms, 4), "algorithmic_bytes_per_launch": algo,
                          "note": "not HBM bound (SURVEY 8d): see roofline_valu and DESIGN.md section 5"},
         }
+        if world > 1:
+            # every rank's own figure (rank 0's `achieved` alone would hide a slow rank): algorithmic GB/s from that rank's HIP-event time
+            ach = [algo / (k * 1e-3) / 1e9 for k in per_rank_kernel_ms]
+            res["roofline"]["per_rank"] = {"kernel_ms_avg": per_rank_kernel_ms, "achieved_min": round(min(ach), 3), "achieved_max": round(max(ach), 3),
+                                           "achieved_sum": round(sum(ach), 3), "frac_of_n_peaks": round(sum(ach) / (HBM_PEAK_GBS * world), 6)}
         if par is not None: res["parity_sample"] = par
         if prof.get("stale"):
             res["roofline"]["traffic_note"] = "profiles/%s_counters.json was collected on other sources (%s, running %s): not quoted" % (PROFILE_ROUND, prof.get("source_head"), source_hash())
@@ -360,11 +438,12 @@ def main():
         if prof.get("valu_insts"):
             # second roofline object: wave-level VALU instruction issue.  peak = 1024 SIMDs x clock / 2 cycles per wave64 VALU op
             # (MI355X_MICROARCH.md constants table: v_fma_f32 wave64 2 cycles on a SIMD-32 with co-resident waves)
-            clk = prof.get("clock_ghz", 2.4)
+            clk = prof.get("clock_ghz", 2.4)                  # measured where the counter pass held GRBM_GUI_ACTIVE (tools/gpu_round.sh), else the nominal 2.4
             peak = 1024 * clk / 2.0
             ach = prof["valu_insts"] / (kern_ms * 1e-3) / 1e9
             res["roofline_valu"] = {"bound": "valu_issue", "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "G wave-instr/s",
                                     "frac": round(ach / peak, 4), "valu_insts_per_launch": prof["valu_insts"], "clock_ghz": clk,
+                                    "clock_source": prof.get("clock_source", "nominal"),
                                     "lane_utilisation": prof.get("valu_lane_util"),
                                     "source": "profiles/%s_counters.json (SQ_INSTS_VALU, separate rocprofv3 --pmc pass of this command)" % PROFILE_ROUND}
             res["roofline_valu"]["source_head"] = prof.get("source_head")
@@ -372,7 +451,7 @@ def main():
             if lu: res["roofline_valu"]["frac_of_lane_peak"] = round(ach / peak * lu, 4)      # 2-cycle VALU peak x the share of lanes the EXEC mask enables
             pk = prof.get("per_kernel") or {}
             counted = sum(v.get(c, 0) for v in pk.values() for c in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD"))
-            if counted:
+            if counted and any("SQ_INSTS_SALU" in v for v in pk.values()):
                 per_cycle = counted / 1024.0 / (kern_ms * 1e-3 * clk * 1e9)
                 res["roofline_valu"]["issue"] = {"insts_per_simd_cycle": round(per_cycle, 3), "counted_insts_per_launch": int(counted),
                                                  "insts_per_frame": round(counted / units, 1),
@@ -405,10 +484,15 @@ def main():
                               "note": "rank 0, same workload through lc3plus_enc_batch_encode with HOST pointers: H2D of PCM, kernels and D2H of frames "
                                       "overlapped in stream chunks (pinned caller buffers; 'pageable' = staged through the library's pinned ring)"}
             # (2) T = 1: one frame per stream per call (SURVEY 8d config 2 'also report T = 1'; BASELINE configs[1] '4096 mono frames')
-            t1 = lambda: batch.encode_device(pcm.data_ptr(), 16, 1, out.data_ptr(), stride, hip_stream=stream.cuda_stream, sync=False)
-            w1 = timed_steps(t1, 200, 20, lambda: torch.cuda.synchronize(dev))
-            res["t1"] = {"value": round(B * 200 / w1 / 1e6, 4), "unit": "Mframes/s", "ms_per_step": round(w1 / 200 * 1e3, 4),
-                         "note": "%d streams x 1 frame per call (launch-latency regime: the kernels of a call run back to back on one stream)" % B}
+            for tn in (1, 4, 8):
+                pc = pcm[:, :tn].contiguous(); oc = torch.zeros(B, tn, stride, dtype=torch.uint8, device=dev)
+                tf = lambda: batch.encode_device(pc.data_ptr(), 16, tn, oc.data_ptr(), stride, hip_stream=stream.cuda_stream, sync=False)
+                wn = timed_steps(tf, 200, 20, lambda: torch.cuda.synchronize(dev))
+                res["t%d" % tn] = {"value": round(B * tn * 200 / wn / 1e6, 4), "unit": "Mframes/s", "ms_per_step": round(wn / 200 * 1e3, 4),
+                                   "host_enqueue_ms_per_step": round(timed_steps.enqueue / 200 * 1e3, 4),
+                                   "note": "%d streams x %d frame(s) per call, calls queued back to back under the input-ready promise (%s)"
+                                           % (B, tn, "one kernel, one channel-stream per wave" if tn <= 5 else "the pipelined kernels")}
+                del pc, oc
         if a.workload == "c1" and not a.no_extras and world == 1:
             # the other BASELINE configurations, ten steps each (their own lines with rooflines: --workload c3 / c4 / c5 / c96)
             res["other_workloads"] = {}

@@ -4,8 +4,9 @@
  * floating-point reference (R = LC3plus_ETSI_src_v17171_20200723/src/floating_point): same symbol,
  * same argument meaning, same LC3_Error values (R/lc3.h:53-75), same ownership rules, so a caller such
  * as R/codec_exe.c links against liblc3plus_hip.so instead of the reference objects.  Behind the ABI
- * every frame is encoded by hand-written gfx950 HIP kernels (one channel-stream per wavefront); there is
- * no CPU fallback: if no MI355X / HIP runtime is available the first lc3_enc_* call that needs the device
+ * every frame is encoded by hand-written gfx950 HIP kernels - a pipeline of kernels, each with the unit of work its dependences allow (one frame per
+ * lane, four frames or one channel-stream per wavefront: DESIGN.md section 3); calls of a few frames and this single-stream API run one kernel with one
+ * channel-stream per wavefront.  There is no CPU fallback: if no MI355X / HIP runtime is available the first lc3_enc_* call that needs the device
  * returns LC3_ERROR and prints a diagnostic.
  *
  * The float decoder (lc3_dec_*, R/lc3.h:318-406) is exported too, for every operating point of the reference.

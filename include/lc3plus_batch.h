@@ -71,7 +71,8 @@ float lc3plus_enc_batch_last_kernel_ms(lc3plus_batch* batch);
 int lc3plus_enc_batch_last_status(lc3plus_batch* batch, uint8_t* status, int max_entries);
 
 /* Diagnostics: the per channel-frame records the kernels of the pipelined path hand to each other, of the last encode() call that took that path
- * (calls of more than 8 frames; 0 words otherwise): host array [n_streams * channels][n_frames][lc3plus_enc_batch_record_words()] of 32-bit words
+ * (calls of more than 8 frames - more than 5 under the input-ready promise - that are neither traced nor run with LC3PLUS_ENC_FUSED / _NO_SPLIT; 0 words when
+ * the last call did not take it): host array [n_streams * channels][n_frames][lc3plus_enc_batch_record_words()] of 32-bit words
  * - 16 scale factors, 16 quantised scale factors, 7 SNS indices, bandwidth index, attack-detector words, 4 LTPF words, 20 TNS words (filters,
  * orders, bits, coefficient indices), gain floor, all-zero flag, bandwidth behind the controller, and gain index / gain / bit count / last
  * non-zero line of the first quantisation (layout: FR_* in audio_codec_amd/csrc/lc3_plan.h).  The stage-level parity tests compare them with the

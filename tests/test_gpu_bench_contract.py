@@ -40,7 +40,7 @@ def test_default_line():
         assert k in c, k
     assert c["kind"] in ("reference", "port") and c["value"] and c["value"] < d["value"]
     assert d["value"] > 30.0                                    # round 1 measured 40; anything below is a regression of the path, not noise
-    for k in ("host_io", "t1", "serial_calls", "parity_sample", "per_rank_ms", "other_workloads"):
+    for k in ("host_io", "t1", "t4", "t8", "serial_calls", "parity_sample", "per_rank_ms", "other_workloads", "host_enqueue_ms_per_step"):
         assert k in d, k
     # counters come from profiles/ and are quoted only when they were collected on the sources that are running (bench.source_hash)
     # (a kernel edit makes the committed counters stale until they are collected again: the line then says so - `traffic_note`, traffic null - and
@@ -50,7 +50,8 @@ def test_default_line():
         assert abs(r["traffic_over_algorithmic"] - r["traffic"] / r["algorithmic_bytes_per_launch"]) < 0.01
     else:
         assert r["traffic"] is None and "roofline_valu" not in d
-    assert d["host_io"]["value"] < d["value"] and d["t1"]["value"] < d["value"]
+    assert d["host_io"]["value"] < d["value"] and d["t1"]["value"] < d["value"] and d["t1"]["host_enqueue_ms_per_step"] > 0
+    assert d["config"]["input_ready"] is True and 0 < d["host_enqueue_ms_per_step"] < d["ms_per_step"] * 1.5
     # the timed launches' own bytes against the CPU oracle: silent, full-scale, periodic and plain streams, all calls of the run
     assert d["parity_sample"]["frames"] >= 5 * 64 and d["parity_sample"]["differ"] == 0, d["parity_sample"]
     assert len(d["per_rank_ms"]) == 1 and abs(d["per_rank_ms"][0] - d["ms_per_step"]) < 0.02 * d["ms_per_step"]
@@ -62,6 +63,7 @@ def test_other_workloads_and_flags():
     d = _run(["--workload", "c3", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extras"])
     assert d["config"]["channels"] == 2 and d["config"]["stereo_frames_per_step_all_gpus"] == 2048 * 16 and "cpu_baseline" not in d
     d = _run(["--workload", "d1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"])
-    assert "decoded" in d["metric"] and (("traffic_note" in d["roofline"]) or (d["roofline"]["traffic"] and "traffic_gbps" in d["roofline"]))
+    assert "decoded" in d["metric"] and (("traffic_note" in d["roofline"]) or d["roofline"]["traffic"] is None or "traffic_gbps" in d["roofline"])
+    assert d["config"]["input_ready"] is True and d["parity_sample"]["frames"] >= 5 * 64 and d["parity_sample"]["differ"] == 0, d.get("parity_sample")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64"], capture_output=True, text=True, timeout=120, cwd=ROOT)
     assert p.returncode == 3 and not p.stdout.strip()           # more ranks than devices: refused, no line

@@ -923,3 +923,71 @@ def test_bandwidth_controller_on_the_pipelined_path(fs, ms, N, bws, ready):
         assert any((got[1, t, :o.nbytes] != o.encode(pcm[1, t][None])).any() for t in range(T))
     finally:
         d.free()
+
+
+def test_rate_chain_stream_choice_switches_between_overlapped_calls():
+    """where the rate chain runs is chosen per call (its own stream for calls of up to 32 frames or a mean frame size of 120 bytes and more, the
+    caller's stream otherwise), so consecutive overlapped calls can alternate between the two: calls of 32 and 33 frames queued back to back under the
+    promise (33, 33, 32, 32, 33, 32: same-length neighbours overlap, the others take the ordered path; the chain crosses streams four times), and a batch
+    whose mean frame size sits at the threshold (80- and 160-byte streams: mean 120).  Bytes of one continuous encode."""
+    amd = _amd()
+    d = _Dev()
+    try:
+        for rates, cuts in (([64000], [33, 33, 32, 32, 33, 32]), ([64000, 128000], [12, 12, 40, 40, 12])):
+            B = 640
+            TT = sum(cuts)
+            pcm = synth_pcm(B, TT, 480, 48000, seed=3233 + len(rates))
+            br = [rates[i % len(rates)] for i in range(B)]
+            b = amd.Batch(B, 48000, 1, 10.0, 0, br, device=0)
+            stride = b.stride
+            b.set_input_ready(True)
+            ins, outs, t0 = [], [], 0
+            for n in cuts:
+                ins.append(d.put(pcm[:, t0:t0 + n])); outs.append(d.zeros(B * n * stride)); t0 += n
+            d.sync()
+            for k, n in enumerate(cuts): b.encode_device(ins[k], 16, n, outs[k], stride, hip_stream=None, sync=False)
+            d.sync()
+            got = np.concatenate([d.get(outs[k], (B, n, stride), np.uint8) for k, n in enumerate(cuts)], axis=1)
+            pick = list(range(0, B, 5))
+            want = _oracle_batch(pcm[pick], 48000, 10.0, 0, [br[i] for i in pick], stride)
+            nb = [b.num_bytes(i) for i in pick]
+            bad = [(i, t) for k, i in enumerate(pick) for t in range(TT) if (got[i, t, :nb[k]] != want[k, t, :nb[k]]).any()]
+            assert not bad, (rates, len(bad), bad[:8])
+            b.close()
+    finally:
+        d.free()
+
+
+def test_check_ready_debug_aid(tmp_path):
+    """LC3PLUS_CHECK_READY=1: with the input-ready promise in force, a device-pointer call made while work of the CALLER is still pending on the stream of the
+    call (here: a large copy queued just before on the same stream) is refused with LC3_ERROR; without pending work the call goes through."""
+    import subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys, ctypes as C, numpy as np
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import audio_codec_amd
+        from lc3_harness import synth_pcm
+        hip = C.CDLL("libamdhip64.so")
+        B, T = 64, 12
+        pcm = synth_pcm(B, T, 480, 48000, seed=5)
+        b = audio_codec_amd.Batch(B, 48000, 1, 10.0, 0, [64000] * B, device=0)
+        st = C.c_void_p(); assert hip.hipStreamCreate(C.byref(st)) == 0
+        pin = C.c_void_p(); pout = C.c_void_p(); big = C.c_void_p(); big2 = C.c_void_p()
+        assert hip.hipMalloc(C.byref(pin), C.c_size_t(pcm.nbytes)) == 0 and hip.hipMalloc(C.byref(pout), C.c_size_t(B * T * b.stride)) == 0
+        assert hip.hipMemcpy(pin, C.c_void_p(pcm.ctypes.data), C.c_size_t(pcm.nbytes), 1) == 0
+        n = 1 << 30
+        assert hip.hipMalloc(C.byref(big), C.c_size_t(n)) == 0 and hip.hipMalloc(C.byref(big2), C.c_size_t(n)) == 0
+        b.set_input_ready(True)
+        b.encode_device(pin.value, 16, T, pout.value, b.stride, hip_stream=st.value, sync=True)          # nothing pending: accepted
+        for _ in range(8): assert hip.hipMemcpyAsync(big2, big, C.c_size_t(n), 3, st) == 0             # the caller's own work on the stream of the call
+        try:
+            b.encode_device(pin.value, 16, T, pout.value, b.stride, hip_stream=st.value, sync=True)
+            print("accepted")
+        except audio_codec_amd.LC3Error:
+            print("refused")
+        assert hip.hipDeviceSynchronize() == 0
+    """ % (root, os.path.join(root, "tests")))
+    e = dict(os.environ); e["LC3PLUS_CHECK_READY"] = "1"
+    r = subprocess.run([sys.executable, "-c", code], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0 and "refused" in r.stdout and "LC3PLUS_CHECK_READY" in r.stderr, (r.stdout[-300:], r.stderr[-800:])

@@ -45,6 +45,57 @@ dist.destroy_process_group()
 '''
 
 
+WORKER_C3 = r'''
+import os, sys, hashlib, ctypes as C
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import numpy as np, torch, torch.distributed as dist
+import bench
+rank, world, local = bench.rank_env()
+dist.init_process_group("gloo")
+plan = bench.rank_plan("c3", rank, world, streams=%(streams)d, frames=%(frames)d)          # bench.py's own plan of BASELINE configs[2], reduced
+pcm = bench.synth_pcm_device(torch, plan["B"], plan["T"], plan["ch"], plan["n"], plan["fs"], torch.device("cpu"), seed=plan["seed"], first_stream=plan["first"]).numpy()
+L = C.CDLL(os.path.join(%(root)r, "oracle", "liblc3_oracle_pm.so"))
+L.lc3o_encode_batch16_ch.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+out = np.zeros((plan["B"], plan["T"], 160), np.uint8)
+br = np.asarray(plan["br"], np.int32)
+def step():
+    assert L.lc3o_encode_batch16_ch(plan["fs"], plan["ms"], plan["hr"], plan["ch"], plan["B"], plan["T"], br.ctypes.data, pcm.ctypes.data, out.ctypes.data, 160) == 0
+wall = bench.timed_steps(step, 1, 1, lambda: None, dist)
+rows = [None] * world
+dist.all_gather_object(rows, (plan["first"], plan["last"], plan["br"], hashlib.md5(out.tobytes()).hexdigest(), int(out.any(axis=2).sum())))
+if rank == 0: print("C3ROWS", repr(rows))
+dist.destroy_process_group()
+'''
+
+
+def test_c3_rank_plan_two_gloo_ranks(tmp_path):
+    """BASELINE configs[2] (262 144 stereo frames over 8 GPUs, no collectives) through bench.py's own rank code on two gloo ranks with the oracle as the
+    step: bench.rank_plan gives every rank its block of the job's streams, its bitrates and its PCM seed; a rank's output depends on its block only (the
+    same block computed alone gives the same bytes); and the full-size plan is 8 x 2048 stereo streams x 16 frames."""
+    import ast, ctypes as C
+    sys.path.insert(0, ROOT)
+    import bench, torch
+    full = [bench.rank_plan("c3", r, 8) for r in range(8)]
+    assert [p["first"] for p in full] == [2048 * r for r in range(8)] and all(p["B"] == 2048 and p["T"] == 16 and p["ch"] == 2 for p in full)
+    assert full[0]["job_streams"] == 16384 and full[0]["job_channel_frames_per_step"] == 2 * 262144 and set(full[3]["br"]) == {128000}
+    script = tmp_path / "worker_c3.py"
+    script.write_text(WORKER_C3 % {"root": ROOT, "streams": 3, "frames": 5})
+    drv = tmp_path / "driver_c3.py"
+    drv.write_text("import sys; sys.path.insert(0, %r); import bench; sys.exit(bench.launch_ranks(2, [], script=%r))\n" % (ROOT, str(script)))
+    out = subprocess.run([sys.executable, str(drv)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rows = ast.literal_eval([l for l in out.stdout.splitlines() if l.startswith("C3ROWS")][0][7:])
+    assert [(r[0], r[1]) for r in rows] == [(0, 3), (3, 6)] and all(r[4] == 3 * 5 for r in rows)          # every stream-frame non-empty
+    L = C.CDLL(os.path.join(ROOT, "oracle", "liblc3_oracle_pm.so"))
+    L.lc3o_encode_batch16_ch.argtypes = [C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    for r in range(2):
+        p = bench.rank_plan("c3", r, 2, streams=3, frames=5)
+        pcm = bench.synth_pcm_device(torch, 3, 5, 2, 480, 48000, torch.device("cpu"), seed=p["seed"], first_stream=p["first"]).numpy()
+        o = np.zeros((3, 5, 160), np.uint8); br = np.asarray(p["br"], np.int32)
+        assert L.lc3o_encode_batch16_ch(48000, 10.0, 0, 2, 3, 5, br.ctypes.data, pcm.ctypes.data, o.ctypes.data, 160) == 0
+        assert hashlib.md5(o.tobytes()).hexdigest() == rows[r][3] and rows[r][2] == p["br"]
+
+
 def test_stream_block_partition():
     for total in (1, 7, 8, 4096, 262144):
         for world in (1, 2, 3, 8):
