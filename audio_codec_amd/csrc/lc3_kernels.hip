@@ -141,7 +141,8 @@ enum { F_HP0 = 0, F_HP1, F_LTPF_NC1, F_LTPF_NC2, F_LTPF_PITCH, F_ATT_M0, F_ATT_M
 enum { I_OLPA_PITCH = 0, I_LTPF_ON, I_ATT_POS, I_ATT_FLAG, I_MEM_TARGET, I_MEM_SPEC,
        I_T0, I_LTPF0, I_LTPF1, I_LTPF2, I_LTPF_BITS, I_BW, I_SCF0, I_SCF1, I_SCF2, I_SCF3, I_SCF4, I_SCF5, I_SCF6,
        I_TNS_NF, I_TNS_ORD0, I_TNS_ORD1, I_TNS_BITS, I_TNS_IDX0 /* 16 entries */, I_GG = I_TNS_IDX0 + 16, I_GGMIN, I_NBITS, I_NBITS2,
-       I_LASTNZ, I_LSB, I_CHANGE, I_FACNS, I_NRES, I_BP_SIDE, I_MASK_SIDE, I_COUNT };
+       I_LASTNZ, I_LSB, I_CHANGE, I_FACNS, I_NRES, I_BP_SIDE, I_MASK_SIDE, I_BUDGET /* st_bitstream: side information + coder bits exceed the frame */, I_COUNT };
+static_assert(I_COUNT <= 56, "isc[] holds 56 words");
 
 /* ------------------------------------------------------------------------------------------------ */
 /* small helpers                                                                                     */
@@ -2552,6 +2553,7 @@ template <class LdsT> STAGE void st_bitstream(const lc3d_plan* __restrict__ P, c
     const int S = w.s8 >> 3;
     const int nbits_ari = 8 * S + 33 - flog2f_int((unsigned)w.range);
     int nres_enc = total - (nbits_side + nbits_ari);
+    if (lane == 0) isc[I_BUDGET] = nres_enc < 0 ? 1 : 0;      /* R/ari_codec.c:777 asserts this; the caller flags the frame */
     nres_enc = imin(nres_enc, lsbMode == 0 ? nres : nl);
     LSYNC();                                        /* LSB list / residual bits and the code value are complete */
     for (int k0 = 32 * lane; k0 < nres_enc; k0 += 32 * WAVE) {
@@ -2896,6 +2898,8 @@ extern "C" __global__ void lc3_enc_front_kernel_big(const lc3d_plan* __restrict_
                                                     int bitdepth, int T, int tb, int nt, int fpw, int ncs, float* __restrict__ spec, int srow, int RT, int r0, float* __restrict__ rec, float* __restrict__ xnext, const float* __restrict__ xprev, int xprev_stride, int do_scf);
 extern "C" __global__ void lc3_enc_shape_kernel_big(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans, int T, int tb, int nt, int fpw, int ncs,
                                                     float* __restrict__ rows, int srow, float* __restrict__ frec);
+extern "C" __global__ void lc3_enc_tailw_kernel_big(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans, int T, int nt, int fpw, int ncs, const float* __restrict__ rows, int srow,
+                                                     const float* __restrict__ frec, uint8_t* __restrict__ out, int out_stride, uint8_t* __restrict__ status, int min_bytes);
 extern "C" __global__ void lc3_enc_rate_kernel_big(const lc3d_plan* __restrict__ P, const lc3d_chan* __restrict__ chans, float* __restrict__ state, int T, int t0, int nt, int ncs,
                                                    const float* __restrict__ rows, int srow, float* __restrict__ frec, const float* __restrict__ xnext, int last);
 #include "lc3_enc_pack.inc"
@@ -2913,7 +2917,7 @@ extern "C" __global__ void lc3_enc_rate_kernel_big(const lc3d_plan* __restrict__
  * that drive two batches never race on them, and a context's behaviour does not change under it. */
 struct lc3hip_opts {
     int fused, no_split, streams5, run_frames, runs, ahead_max, rate_stream /* -1 rule, 0, 1 */, pre_runs, pitch2, scf_wave, front4, shape_fpw, shape_on_s, shape_wave,
-        pack_wpg, pack_stream /* -1 off (default), 0, 1 */, resample48, dec_imdct4, check_ready;
+        pack_wpg, pack_stream /* -1 off (default), 0, 1 */, resample48, dec_imdct4, check_ready, tailw_bytes;
 };
 static int env_int(const char* name, int lo, int hi, int dflt) { const char* e = getenv(name); if (!e || !*e) return dflt; const int v = atoi(e); return v >= lo && v <= hi ? v : dflt; }
 static void read_opts(lc3hip_opts* o)
@@ -2935,6 +2939,10 @@ static void read_opts(lc3hip_opts* o)
     o->pack_wpg = env_int("LC3PLUS_ENC_PACK_WPG", 1, 4, 4);          /* waves per workgroup of the writer */
     o->pack_stream = env_int("LC3PLUS_ENC_PACK_STREAM", 0, 1, -1);   /* 1 = the writers of consecutive calls on two side streams (deployment switch, see enc_launch) */
     o->resample48 = env_int("LC3PLUS_ENC_RESAMPLE48", 0, 1, 1);      /* 0 = the two-outputs-per-lane resampler for 48 kHz / 10 ms too */
+    /* frames of this size and more: tail + writer a frame per wave (lc3_enc_tailw_kernel).  Off (0) by default - measured, Mframes/s: c96 (320-byte frames) 32.5 without,
+     * 27.3 with; c5 (20 ... 400 bytes) 86.5 without, 68.6 / 73.6 / 78.4 from 120 / 200 / 320 bytes: the wave-parallel writer shortens the longest wave of the call but
+     * costs several times the instructions per frame, and the call is bound by instructions, not by that latency. */
+    o->tailw_bytes = env_int("LC3PLUS_ENC_TAILW_BYTES", 0, 1 << 20, 0);
     o->check_ready = env_int("LC3PLUS_CHECK_READY", 0, 1, 0);        /* debug aid for lc3plus_enc_batch_set_input_ready: refuse a call made while foreign work is pending on the caller's stream */
     o->dec_imdct4 = env_int("LC3PLUS_DEC_IMDCT4", 0, 1, 1);          /* 0 = the one-frame-at-a-time IMDCT for N = 480 too */
 }
@@ -2952,7 +2960,7 @@ struct lc3hip_ctx {
     /* host-pointer pipeline (lc3hip_encode_host): two chunk slots, each with device staging and (for pageable callers) pinned staging */
     void* hp_dpcm[2]; void* hp_pin_in[2]; size_t hp_pcm_cap, hp_pin_in_cap;
     hipStream_t s_h2d; hipEvent_t ev_h2d[2], ev_k[2];
-    hipStream_t s_pre, s_fr, s_pit, s_ln, s_rt; hipEvent_t ev_rate; int rate_armed, mean_nbytes; int* h_nb; hipEvent_t ev_fork, ev_p[LC3D_MAX_RUNS], ev_f[LC3D_MAX_RUNS], ev_h[LC3D_MAX_RUNS], ev_m[LC3D_MAX_RUNS];   /* side streams: pitch chain, frame-parallel front, frame-parallel tail */
+    hipStream_t s_pre, s_fr, s_pit, s_ln, s_rt; hipEvent_t ev_rate; int rate_armed, mean_nbytes, min_nbytes, max_nbytes; int* h_nb; hipEvent_t ev_fork, ev_p[LC3D_MAX_RUNS], ev_f[LC3D_MAX_RUNS], ev_h[LC3D_MAX_RUNS], ev_m[LC3D_MAX_RUNS];   /* side streams: pitch chain, frame-parallel front, frame-parallel tail */
     int ylen, srow, la, len12, fm_frames; const float* last_frec; int last_frec_frames;      /* the records of the last pipelined call (lc3hip_last_records) */
     hipStream_t stream, last_stream; hipEvent_t ev0, ev1; float last_ms;
     hipEvent_t ev_ours, ev_now; int ours_armed;       /* LC3PLUS_CHECK_READY: the tail of the library's own work on the caller's stream */
@@ -3027,7 +3035,8 @@ extern "C" int lc3hip_upload_chans(void* ctx, const lc3d_chan* chans, int first,
     /* mean frame size: decides where the rate chain runs (enc_launch) */
     if (!c->h_nb) { c->h_nb = (int*)calloc((size_t)c->ncs, sizeof(int)); if (!c->h_nb) return 1; }
     for (int i = 0; i < count; i++) c->h_nb[first + i] = chans[i].nbytes;
-    { long long sum = 0; for (int i = 0; i < c->ncs; i++) sum += c->h_nb[i]; c->mean_nbytes = (int)(sum / (c->ncs > 0 ? c->ncs : 1)); }
+    { long long sum = 0; int mn = 1 << 30, mx = 0; for (int i = 0; i < c->ncs; i++) { sum += c->h_nb[i]; if (c->h_nb[i] < mn) mn = c->h_nb[i]; if (c->h_nb[i] > mx) mx = c->h_nb[i]; }
+      c->mean_nbytes = (int)(sum / (c->ncs > 0 ? c->ncs : 1)); c->min_nbytes = mn; c->max_nbytes = mx; }
     return 0;
 }
 
@@ -3267,8 +3276,18 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
             HIPCHK(hipStreamWaitEvent(ps, c->ev_rate, 0));
         }
         if (split) HIPCHK(hipMemsetAsync(c->d_status, 0, (size_t)c->ncs * dT, ps));
+        /* large frames: tail + writer a frame per wave (lc3_enc_tailw_kernel, lc3_enc_rate.inc), launched first - its waves are the long ones */
+        const int big_from = (split && c->opt.tailw_bytes && c->max_nbytes >= c->opt.tailw_bytes) ? c->opt.tailw_bytes : 0;
+        if (big_from) {
+            const int fpw = dT < 4 ? dT : 4;
+            const unsigned wruns = (unsigned)((dT + fpw - 1) / fpw);
+            if (c->big) hipLaunchKernelGGL(lc3_enc_tailw_kernel_big, dim3((unsigned)c->ncs * wruns), dim3(WAVE), 0, ps, c->d_plan, c->d_chans, dT, dT, fpw, c->ncs, rows_for_pack, c->srow, frec_for_pack, dout, out_stride, c->d_status, big_from);
+            else hipLaunchKernelGGL(lc3_enc_tailw_kernel, dim3((unsigned)c->ncs * wruns), dim3(WAVE), 0, ps, c->d_plan, c->d_chans, dT, dT, fpw, c->ncs, rows_for_pack, c->srow, frec_for_pack, dout, out_stride, c->d_status, big_from);
+            HIPCHK(hipGetLastError());
+        }
+        if (!big_from || c->min_nbytes < big_from)
         DUPL('k') hipLaunchKernelGGL(lc3_enc_pack_kernel, dim3((unsigned)((tasks + per_wg - 1) / per_wg)), dim3(wpg * WAVE), per_wave * wpg, ps, c->d_plan, c->d_chans, ddump, dstride,
-                           dT, 0, dT, c->ncs, dout, out_stride, c->d_status, rows_for_pack, c->srow, frec_for_pack);
+                           dT, 0, dT, c->ncs, dout, out_stride, c->d_status, rows_for_pack, c->srow, frec_for_pack, big_from);
         if (split && c->input_ready) { HIPCHK(hipEventRecord(c->ev_done[c->row_par], ps)); c->row_par = (c->row_par + 1) % LC3D_SETS; }      /* this call's set of rows and records is free again */
         if (side) { HIPCHK(hipEventRecord(c->ev_pk[c->pk_par], ps)); HIPCHK(hipStreamWaitEvent(s, c->ev_pk[c->pk_par], 0)); c->pk_par ^= 1; }
     }

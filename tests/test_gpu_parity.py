@@ -991,3 +991,32 @@ def test_check_ready_debug_aid(tmp_path):
     e = dict(os.environ); e["LC3PLUS_CHECK_READY"] = "1"
     r = subprocess.run([sys.executable, "-c", code], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert r.returncode == 0 and "refused" in r.stdout and "LC3PLUS_CHECK_READY" in r.stderr, (r.stdout[-300:], r.stderr[-800:])
+
+
+def test_wave_per_frame_tail_writer_switch(tmp_path):
+    """LC3PLUS_ENC_TAILW_BYTES=N: channel-streams with frames of N bytes and more get lc3_enc_tailw_kernel (tail of the encoder + wave-parallel range coder, a frame
+    per wave) instead of a lane of lc3_enc_pack_kernel; the two kernels split a mixed batch.  Same bytes as the oracle, and the status bytes stay clear."""
+    import subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import audio_codec_amd
+        from lc3_harness import synth_pcm
+        from test_gpu_parity import _oracle_batch, RATES
+        for fs, ms, hr, N, rates in ((48000, 10.0, 0, 480, RATES), (96000, 10.0, 1, 960, [256000, 149600, 400000]), (32000, 5.0, 0, 160, [64000, 192000, 320000])):
+            B, T = 96, 14
+            br = [rates[i %% len(rates)] for i in range(B)]
+            pcm = synth_pcm(B, T, N, fs, seed=1717)
+            b = audio_codec_amd.Batch(B, fs, 1, ms, hr, br, device=0)
+            got = np.concatenate([b.encode(pcm[:, :T]), b.encode(pcm[:, :T])], axis=1)
+            assert not b.last_status(T).any()
+            want = _oracle_batch(np.concatenate([pcm, pcm], axis=1), fs, ms, hr, br, b.stride)
+            nb = [b.num_bytes(i) for i in range(B)]
+            bad = [(i, t) for i in range(B) for t in range(2 * T) if (got[i, t, :nb[i]] != want[i, t, :nb[i]]).any()]
+            assert not bad, (fs, ms, bad[:6])
+        print("ok")
+    """ % (root, os.path.join(root, "tests")))
+    e = dict(os.environ); e["LC3PLUS_ENC_TAILW_BYTES"] = "100"
+    r = subprocess.run([sys.executable, "-c", code], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-300:], r.stderr[-800:])
