@@ -48,6 +48,32 @@ LC3M_FN double lc3m_poly8(const double* __restrict__ c, double r)
     p = __builtin_fma(p, r, c[3]); p = __builtin_fma(p, r, c[2]); p = __builtin_fma(p, r, c[1]); p = __builtin_fma(p, r, c[0]);
     return p;
 }
+/* Branch-free forms for code that evaluates several logarithms in a row (a branch per call keeps the compiler from overlapping their table reads): the
+ * result for a positive finite x, anything for the rest; *special is set for the rest, and the caller takes lc3m_log*f() for those afterwards (rare: one
+ * wave-level test behind the group). */
+LC3M_FN double lc3m_log_reduce_nb(float x, const double* __restrict__ tab, double* kd, double* hi, double* lo, int* special)
+{
+    const uint64_t ix = lc3m_bits((double)x);
+    *special = !(ix - 0x0010000000000000ULL < 0x7FE0000000000000ULL);
+    const uint64_t tmp = ix - 0x3FE6000000000000ULL;
+    const int i = (int)(tmp >> 45) & 127;
+    const double z = lc3m_dbl(ix - (tmp & 0xFFF0000000000000ULL));
+    const double* T = tab + 3 * i;
+    *hi = T[1]; *lo = T[2]; *kd = (double)(int)((int64_t)tmp >> 52);
+    return __builtin_fma(z, T[0], -1.0);
+}
+LC3M_FN float lc3m_log2f_nb(float x, const double* __restrict__ tab, int* special)
+{
+    double kd, hi, lo;
+    const double r = lc3m_log_reduce_nb(x, tab, &kd, &hi, &lo, special);
+    return (float)((kd + hi) + __builtin_fma(r, lc3m_poly8(lc3m_log2_poly, r), lo));
+}
+LC3M_FN float lc3m_log10f_nb(float x, const double* __restrict__ tab, int* special)
+{
+    double kd, hi, lo;
+    const double r = lc3m_log_reduce_nb(x, tab, &kd, &hi, &lo, special);
+    return (float)(__builtin_fma(kd, LC3M_LOG10_2_HI, hi) + __builtin_fma(r, lc3m_poly8(lc3m_log10_poly, r), __builtin_fma(kd, LC3M_LOG10_2_LO, lo)));
+}
 /* (float)log2((double)x); tab = lc3m_log2_tab or a copy of it */
 LC3M_FN float lc3m_log2f(float x, const double* __restrict__ tab)
 {

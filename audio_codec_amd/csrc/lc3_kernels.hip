@@ -25,6 +25,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <stddef.h>
+#include <type_traits>
 
 #define LC3T_QUAL static __device__ const
 #include "lc3_fastmath.h"
@@ -150,10 +151,16 @@ static_assert(I_COUNT <= 56, "isc[] holds 56 words");
 /* (float)f((double)x) for f = log2, log10, 2^x: lc3_fastmath.h - a dozen double-precision fused multiply-adds behind a table, bit-identical to glibc's
  * log2 / log10 / exp2 / pow(2, .) for EVERY float argument (tools/fastmath_check.c), instead of the device library's 40 ... 80 fp64 instructions.  The
  * one-frame-per-lane kernels read the tables from LDS copies (m_*_t), everything else from global memory (a gather per call). */
+#ifdef LC3_OCML_MATH      /* diagnostic builds (tools/variants.sh): the device library's double functions, as until round 3 */
+__device__ __forceinline__ float m_log2f(float x) { return (float)log2((double)x); }
+__device__ __forceinline__ float m_log10f(float x) { return (float)log10((double)x); }
+__device__ __forceinline__ float m_pow2f(float y) { return (float)exp2((double)y); }
+#else
 __device__ __forceinline__ float m_log2f(float x) { return lc3m_log2f(x, lc3m_log2_tab); }
 __device__ __forceinline__ float m_log10f(float x) { return lc3m_log10f(x, lc3m_log10_tab); }
-__device__ __forceinline__ float m_powf(float x, float y) { return (float)pow((double)x, (double)y); }
 __device__ __forceinline__ float m_pow2f(float y) { return lc3m_exp2f(y, lc3m_exp2_tab); }
+#endif
+__device__ __forceinline__ float m_powf(float x, float y) { return (float)pow((double)x, (double)y); }
 __device__ __forceinline__ float mul_d(float a, double c) { return (float)((double)a * c); }
 __device__ __forceinline__ int imin(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }

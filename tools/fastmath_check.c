@@ -1,7 +1,7 @@
 /* tools/fastmath_check.c -- TEST INFRASTRUCTURE: audio_codec_amd/csrc/lc3_fastmath.h against glibc for EVERY float argument.
  *   gcc -O2 -ffp-contract=off -mfma -pthread -Iaudio_codec_amd/csrc tools/fastmath_check.c -o /tmp/fastmath_check -lm
  *   /tmp/fastmath_check [threads] [stride]      stride 1 = exhaustive (about 6.4e9 evaluations), stride n = every n-th bit pattern
- * log2 / log10: all positive finite floats (subnormals included); exp2: all floats in [-160, 160] (beyond that both sides give 0 / inf, checked at the
+ * log2 / log10: all positive finite floats (subnormals included), the branch-free forms (lc3m_log*f_nb) checked beside them; exp2: all floats in [-160, 160] (beyond that both sides give 0 / inf, checked at the
  * ends), once against exp2 and once against pow(2, x), which is what the oracle calls.  Prints the number of arguments whose results differ in any bit and the first of them.  Exit code 1 when anything differs. */
 #define _GNU_SOURCE
 #include <pthread.h>
@@ -19,8 +19,9 @@ static void* work(void* a)
     for (uint64_t u = j->lo; u < j->hi; u += j->stride) {
         const float x = asf((uint32_t)u);
         float got, want;
-        if (j->fn == 0) { got = lc3m_log2f(x, lc3m_log2_tab); want = (float)log2((double)x); }
-        else if (j->fn == 1) { got = lc3m_log10f(x, lc3m_log10_tab); want = (float)log10((double)x); }
+        int sp = 0;
+        if (j->fn == 0) { got = lc3m_log2f(x, lc3m_log2_tab); want = (float)log2((double)x); if (asu(lc3m_log2f_nb(x, lc3m_log2_tab, &sp)) != asu(got) || sp) got = 0.0f / 0.0f; }
+        else if (j->fn == 1) { got = lc3m_log10f(x, lc3m_log10_tab); want = (float)log10((double)x); if (asu(lc3m_log10f_nb(x, lc3m_log10_tab, &sp)) != asu(got) || sp) got = 0.0f / 0.0f; }
         else if (j->fn == 2) { got = lc3m_exp2f(x, lc3m_exp2_tab); want = (float)exp2((double)x); }
         else { got = lc3m_exp2f(x, lc3m_exp2_tab); want = (float)pow(2.0, (double)x); }      /* what oracle/lc3_oracle.c's m_powf(2, x) evaluates */
         j->n++;
