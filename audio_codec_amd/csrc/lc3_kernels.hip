@@ -2924,7 +2924,7 @@ extern "C" __global__ void lc3_enc_rate_kernel_big(const lc3d_plan* __restrict__
  * that drive two batches never race on them, and a context's behaviour does not change under it. */
 struct lc3hip_opts {
     int fused, no_split, streams5, run_frames, runs, ahead_max, rate_stream /* -1 rule, 0, 1 */, pre_runs, pitch2, scf_wave, front4, shape_fpw, shape_on_s, shape_wave,
-        pack_wpg, pack_stream /* -1 off (default), 0, 1 */, resample48, dec_imdct4, check_ready, tailw_bytes;
+        pack_wpg, pack_stream /* -1 off (default), 0, 1 */, resample48, dec_imdct4, check_ready, tailw_bytes, dec_parse_pad_kb, pack_pad_kb;
 };
 static int env_int(const char* name, int lo, int hi, int dflt) { const char* e = getenv(name); if (!e || !*e) return dflt; const int v = atoi(e); return v >= lo && v <= hi ? v : dflt; }
 static void read_opts(lc3hip_opts* o)
@@ -2950,6 +2950,8 @@ static void read_opts(lc3hip_opts* o)
      * 27.3 with; c5 (20 ... 400 bytes) 86.5 without, 68.6 / 73.6 / 78.4 from 120 / 200 / 320 bytes: the wave-parallel writer shortens the longest wave of the call but
      * costs several times the instructions per frame, and the call is bound by instructions, not by that latency. */
     o->tailw_bytes = env_int("LC3PLUS_ENC_TAILW_BYTES", 0, 1 << 20, 0);
+    o->dec_parse_pad_kb = env_int("LC3PLUS_DEC_PARSE_PAD_KB", 0, 60, -1);  /* LDS padding per parse workgroup = fewer resident parse waves; -1: the rule in lc3hip_dec_decode */
+    o->pack_pad_kb = env_int("LC3PLUS_ENC_PACK_PAD_KB", 0, 60, -1);      /* LDS padding per writer workgroup = fewer resident writer waves; -1: the rule in enc_launch */
     o->check_ready = env_int("LC3PLUS_CHECK_READY", 0, 1, 0);        /* debug aid for lc3plus_enc_batch_set_input_ready: refuse a call made while foreign work is pending on the caller's stream */
     o->dec_imdct4 = env_int("LC3PLUS_DEC_IMDCT4", 0, 1, 1);          /* 0 = the one-frame-at-a-time IMDCT for N = 480 too */
 }
@@ -3293,7 +3295,7 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
             HIPCHK(hipGetLastError());
         }
         if (!big_from || c->min_nbytes < big_from)
-        DUPL('k') hipLaunchKernelGGL(lc3_enc_pack_kernel, dim3((unsigned)((tasks + per_wg - 1) / per_wg)), dim3(wpg * WAVE), per_wave * wpg, ps, c->d_plan, c->d_chans, ddump, dstride,
+        DUPL('k') hipLaunchKernelGGL(lc3_enc_pack_kernel, dim3((unsigned)((tasks + per_wg - 1) / per_wg)), dim3(wpg * WAVE), per_wave * wpg + ((size_t)(c->opt.pack_pad_kb > 0 ? c->opt.pack_pad_kb : 0) << 10), ps, c->d_plan, c->d_chans, ddump, dstride,
                            dT, 0, dT, c->ncs, dout, out_stride, c->d_status, rows_for_pack, c->srow, frec_for_pack, big_from);
         if (split && c->input_ready) { HIPCHK(hipEventRecord(c->ev_done[c->row_par], ps)); c->row_par = (c->row_par + 1) % LC3D_SETS; }      /* this call's set of rows and records is free again */
         if (side) { HIPCHK(hipEventRecord(c->ev_pk[c->pk_par], ps)); HIPCHK(hipStreamWaitEvent(s, c->ev_pk[c->pk_par], 0)); c->pk_par ^= 1; }
@@ -3665,9 +3667,14 @@ extern "C" int lc3hip_dec_decode(void* ctx, const void* frames, int frames_on_de
     /* parse: one stream-frame per lane; concealment bookkeeping: one channel-stream per lane; IMDCT: one channel-frame per wave;
      * synthesis: one channel-stream per wave (lc3_dec_kernels.inc) */
     if (ahead && c->free_armed[c->set]) HIPCHK(hipStreamWaitEvent(sp, c->ev_free[c->set], 0));      /* this set was last read by the synthesis of the call before the previous one */
-    if (nw_max) hipLaunchKernelGGL(lc3_dec_parse_kernel, dim3((unsigned)((tasks + per_wg - 1) / per_wg)), dim3(wpg * WAVE), per_wave * wpg, sp, c->d_plan, c->d_chans, din, in_stride,
+    /* How many parse waves a CU holds.  The kernel for frames of more than 128 bytes reads its frames from global memory and needs little LDS, so its 4 096
+     * waves of 128 registers fill every SIMD, and the 64-wave concealment kernel and the transform of the call before wait for parse waves to retire; 24 KB of
+     * padding per workgroup leave room beside them: d5 81.3 -> 88.7 Mframes/s (20 KB: 87.1, 28 KB: 77.1).  The kernel that stages its frames in LDS (d1) loses
+     * with any padding (129 -> 117 at 16 KB): none there. */
+    const size_t pad = (size_t)(c->opt.dec_parse_pad_kb >= 0 ? c->opt.dec_parse_pad_kb : (nw_max ? 0 : 24)) << 10;
+    if (nw_max) hipLaunchKernelGGL(lc3_dec_parse_kernel, dim3((unsigned)((tasks + per_wg - 1) / per_wg)), dim3(wpg * WAVE), per_wave * wpg + pad, sp, c->d_plan, c->d_chans, din, in_stride,
                                    dbfi, n_frames, c->n_streams, nw_max, rec_w, ws_w, WS_ROW(c->N));
-    else hipLaunchKernelGGL(lc3_dec_parse_kernel_g, dim3((unsigned)((tasks + per_wg - 1) / per_wg)), dim3(wpg * WAVE), per_wave * wpg, sp, c->d_plan, c->d_chans, din, in_stride,
+    else hipLaunchKernelGGL(lc3_dec_parse_kernel_g, dim3((unsigned)((tasks + per_wg - 1) / per_wg)), dim3(wpg * WAVE), per_wave * wpg + pad, sp, c->d_plan, c->d_chans, din, in_stride,
                             dbfi, n_frames, c->n_streams, nw_max, rec_w, ws_w, WS_ROW(c->N));
     HIPCHK(hipGetLastError());
     if (ahead) { HIPCHK(hipEventRecord(c->ev_par[c->set], sp)); HIPCHK(hipStreamWaitEvent(s, c->ev_par[c->set], 0)); }
