@@ -2981,6 +2981,23 @@ struct lc3hip_ctx {
 /* inside the create functions: release what has been allocated so far (the caller only sees ctx == NULL) */
 #define HIPCHK_OR(x, cleanup) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "lc3plus_hip: %s failed: %s (%s:%d)\n", #x, hipGetErrorString(e_), __FILE__, __LINE__); cleanup; return 1; } } while (0)
 
+/* test hook (tests/test_gpu_parity.py::test_device_fastmath_equals_host): lc3_fastmath.h as the kernels evaluate it, over an array.  kind 0 log2, 1 log10, 2 2^x */
+extern "C" __global__ void lc3_fastmath_test_kernel(int kind, const float* __restrict__ x, float* __restrict__ y, long long n)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = kind == 0 ? m_log2f(x[i]) : kind == 1 ? m_log10f(x[i]) : m_pow2f(x[i]);
+}
+extern "C" int lc3hip_test_fastmath(int kind, const float* x_host, float* y_host, long long n)
+{
+    float *dx = nullptr, *dy = nullptr;
+    HIPCHK(hipMalloc((void**)&dx, (size_t)n * 4)); HIPCHK(hipMalloc((void**)&dy, (size_t)n * 4));
+    HIPCHK(hipMemcpy(dx, x_host, (size_t)n * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(lc3_fastmath_test_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, kind, dx, dy, n);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpy(y_host, dy, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipFree(dx)); HIPCHK(hipFree(dy));
+    return 0;
+}
 extern "C" int lc3hip_destroy(void* ctx);
 extern "C" int lc3hip_create(void** out_ctx, const lc3d_plan* plan, int n_streams, int device)
 {

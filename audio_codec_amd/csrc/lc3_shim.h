@@ -47,6 +47,7 @@ int   lc3hip_set_input_ready(void* ctx, int ready);              /* see lc3plus_
 int   lc3hip_last_status(void* ctx, uint8_t* status_host, int n);        /* LC3D_ENC_ST_* bits per channel-frame of the last call; returns the count copied */
 int   lc3hip_last_records(void* ctx, float* rec_host, int max_words);   /* the per-frame records of the last pipelined call [channel-stream][frame][FR_WORDS]; returns the words copied (0: the last call did not take that path) */
 int   lc3hip_destroy(void* ctx);
+int   lc3hip_test_fastmath(int kind, const float* x_host, float* y_host, long long n);   /* test hook: lc3_fastmath.h on the device over an array (0 log2, 1 log10, 2 2^x) */
 #ifdef __cplusplus
 }
 #endif

@@ -1020,3 +1020,25 @@ def test_wave_per_frame_tail_writer_switch(tmp_path):
     e = dict(os.environ); e["LC3PLUS_ENC_TAILW_BYTES"] = "100"
     r = subprocess.run([sys.executable, "-c", code], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert r.returncode == 0 and "ok" in r.stdout, (r.stdout[-300:], r.stderr[-800:])
+
+
+def test_device_fastmath_equals_host(tmp_path):
+    """lc3_fastmath.h gives the same bits on the device as on the host (which tools/fastmath_check.c pins to glibc for every float argument): half a million
+    arguments per function - every binade, the neighbourhood of 1 and of the powers of two, subnormals, the special arguments - through the library's test hook."""
+    import ctypes as C
+    sys_path = os.path.join(os.path.dirname(os.path.abspath(__file__)))
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("test_fastmath", os.path.join(sys_path, "test_fastmath.py"))
+    tf = importlib.util.module_from_spec(spec); spec.loader.exec_module(tf)
+    H = tf.host_lib(tmp_path)
+    L = _amd().load_library()
+    L.lc3hip_test_fastmath.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_longlong]
+    logs, ex = tf.sample_arguments(seed=11)
+    sp = np.array([0.0, -0.0, -1.0, np.inf, -np.inf, np.nan, 1e30, -1e30, 2000.0, -2000.0], np.float32)
+    for kind, x in ((0, np.concatenate([logs, sp])), (1, np.concatenate([logs, sp])), (2, np.concatenate([ex, sp]))):
+        x = np.ascontiguousarray(x)
+        dev = np.zeros_like(x); host = np.zeros_like(x)
+        assert L.lc3hip_test_fastmath(kind, x.ctypes.data, dev.ctypes.data, x.size) == 0
+        H.lc3m_host_eval(kind, x.ctypes.data, host.ctypes.data, x.size)
+        same = (dev.view(np.uint32) == host.view(np.uint32)) | (np.isnan(dev) & np.isnan(host))
+        assert same.all(), (kind, x[~same][:6], dev[~same][:6], host[~same][:6])
