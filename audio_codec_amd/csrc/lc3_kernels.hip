@@ -2924,7 +2924,7 @@ extern "C" __global__ void lc3_enc_rate_kernel_big(const lc3d_plan* __restrict__
  * that drive two batches never race on them, and a context's behaviour does not change under it. */
 struct lc3hip_opts {
     int fused, no_split, streams5, run_frames, runs, ahead_max, rate_stream /* -1 rule, 0, 1 */, pre_runs, pitch2, scf_wave, front4, shape_fpw, shape_on_s, shape_wave,
-        pack_wpg, pack_stream /* -1 off (default), 0, 1 */, resample48, dec_imdct4, check_ready, tailw_bytes, dec_parse_pad_kb, pack_pad_kb;
+        pack_wpg, pack_stream /* -1 off (default), 0, 1 */, resample48, dec_imdct4, check_ready, tailw_bytes, dec_parse_pad_kb, pack_pad_kb, pack_split, pack_w5;
 };
 static int env_int(const char* name, int lo, int hi, int dflt) { const char* e = getenv(name); if (!e || !*e) return dflt; const int v = atoi(e); return v >= lo && v <= hi ? v : dflt; }
 static void read_opts(lc3hip_opts* o)
@@ -2952,6 +2952,8 @@ static void read_opts(lc3hip_opts* o)
     o->tailw_bytes = env_int("LC3PLUS_ENC_TAILW_BYTES", 0, 1 << 20, 0);
     o->dec_parse_pad_kb = env_int("LC3PLUS_DEC_PARSE_PAD_KB", 0, 60, -1);  /* LDS padding per parse workgroup = fewer resident parse waves; -1: the rule in lc3hip_dec_decode */
     o->pack_pad_kb = env_int("LC3PLUS_ENC_PACK_PAD_KB", 0, 60, -1);      /* LDS padding per writer workgroup = fewer resident writer waves; -1: the rule in enc_launch */
+    o->pack_split = env_int("LC3PLUS_ENC_PACK_SPLIT", 0, 1, -1);        /* the writer as two kernels (head, coder); -1: the rule in enc_launch */
+    o->pack_w5 = env_int("LC3PLUS_ENC_PACK_W5", 0, 1, -1);              /* the writer under a 96-register budget; -1: the rule in enc_launch (long calls of small 10 ms frames) */
     o->check_ready = env_int("LC3PLUS_CHECK_READY", 0, 1, 0);        /* debug aid for lc3plus_enc_batch_set_input_ready: refuse a call made while foreign work is pending on the caller's stream */
     o->dec_imdct4 = env_int("LC3PLUS_DEC_IMDCT4", 0, 1, 1);          /* 0 = the one-frame-at-a-time IMDCT for N = 480 too */
 }
@@ -3311,9 +3313,21 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
             else hipLaunchKernelGGL(lc3_enc_tailw_kernel, dim3((unsigned)c->ncs * wruns), dim3(WAVE), 0, ps, c->d_plan, c->d_chans, dT, dT, fpw, c->ncs, rows_for_pack, c->srow, frec_for_pack, dout, out_stride, c->d_status, big_from);
             HIPCHK(hipGetLastError());
         }
-        if (!big_from || c->min_nbytes < big_from)
-        DUPL('k') hipLaunchKernelGGL(lc3_enc_pack_kernel, dim3((unsigned)((tasks + per_wg - 1) / per_wg)), dim3(wpg * WAVE), per_wave * wpg + ((size_t)(c->opt.pack_pad_kb > 0 ? c->opt.pack_pad_kb : 0) << 10), ps, c->d_plan, c->d_chans, ddump, dstride,
-                           dT, 0, dT, c->ncs, dout, out_stride, c->d_status, rows_for_pack, c->srow, frec_for_pack, big_from);
+        const bool two = split && c->opt.pack_split == 1;
+        if (!big_from || c->min_nbytes < big_from) {
+            const dim3 grid((unsigned)((tasks + per_wg - 1) / per_wg)), block(wpg * WAVE);
+            const size_t dyn = per_wave * wpg + ((size_t)(c->opt.pack_pad_kb > 0 ? c->opt.pack_pad_kb : 0) << 10);
+            if (two) {
+                hipLaunchKernelGGL(lc3_enc_pack_head_kernel, grid, block, 0, ps, c->d_plan, c->d_chans, ddump, dstride, dT, 0, dT, c->ncs, dout, out_stride, c->d_status, rows_for_pack, c->srow, frec_for_pack, big_from);
+                hipLaunchKernelGGL(lc3_enc_pack_code_kernel, grid, block, dyn, ps, c->d_plan, c->d_chans, ddump, dstride, dT, 0, dT, c->ncs, dout, out_stride, c->d_status, rows_for_pack, c->srow, frec_for_pack, big_from);
+            } else {
+                /* 96 or 128 registers (lc3_enc_pack.inc, the table at lc3_enc_pack_kernel_w5): five waves per SIMD pay for long calls of small 10 ms frames */
+                const bool w5 = c->opt.pack_w5 >= 0 ? c->opt.pack_w5 == 1 : (split && !c->big && !c->hr && c->N == 480 && dT >= 48 && c->max_nbytes <= 100);
+                auto pk = w5 ? lc3_enc_pack_kernel_w5 : lc3_enc_pack_kernel;
+                DUPL('k') hipLaunchKernelGGL(pk, grid, block, dyn, ps, c->d_plan, c->d_chans, ddump, dstride,
+                                   dT, 0, dT, c->ncs, dout, out_stride, c->d_status, rows_for_pack, c->srow, frec_for_pack, big_from);
+            }
+        }
         if (split && c->input_ready) { HIPCHK(hipEventRecord(c->ev_done[c->row_par], ps)); c->row_par = (c->row_par + 1) % LC3D_SETS; }      /* this call's set of rows and records is free again */
         if (side) { HIPCHK(hipEventRecord(c->ev_pk[c->pk_par], ps)); HIPCHK(hipStreamWaitEvent(s, c->ev_pk[c->pk_par], 0)); c->pk_par ^= 1; }
     }

@@ -90,6 +90,8 @@ def rank_plan(workload, rank, world, streams=0, frames=0):
     fs, ms, hr, ch, n, rates, T, B, what = WORKLOADS[workload]
     if frames: T = frames
     if streams: B = streams
+    if os.environ.get("LC3_BENCH_RATES"):           # diagnostic sweeps (tools/): the workload's shape at other bitrates; the line's config.bytes_per_frame says what ran
+        rates = [int(v) for v in os.environ["LC3_BENCH_RATES"].split(",")]
     first, last = stream_block(rank, world, B * world)
     assert last - first == B
     return {"fs": fs, "ms": ms, "hr": hr, "ch": ch, "n": n, "T": T, "B": B, "what": what, "first": first, "last": last,
