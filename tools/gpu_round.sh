@@ -52,7 +52,7 @@ for w in "$WL".split():
             k = r["Kernel_Name"].split("(")[0]
             if k.startswith("lc3_dec" if w[0] == "d" else "lc3_enc"):
                 per[(k, r["Counter_Name"])] += float(r["Counter_Value"])
-                if k.split("_big")[0] in ("lc3_enc_pack_kernel", "lc3_dec_synth_kernel"): calls[r["Counter_Name"]] += 1
+                if k.startswith("lc3_enc_pack_kernel") or k.startswith("lc3_dec_synth_kernel"): calls[r["Counter_Name"]] += 1      # (also lc3_enc_pack_kernel_w5, the _big synthesis kernel)
                 # effective clock (MI355X_MICROARCH.md "DVFS give-back"): GRBM_GUI_ACTIVE is summed over the 8 XCDs; dispatches of 0.3 ms and more only
                 if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
                     d = float(r["End_Timestamp"]) - float(r["Start_Timestamp"])

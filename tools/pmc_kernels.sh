@@ -24,7 +24,7 @@ for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
         k = r["Kernel_Name"].split("(")[0]
         if not k.startswith("lc3_"): continue
         per[(k, r["Counter_Name"])] += float(r["Counter_Value"])
-        if k in ("lc3_enc_pack_kernel", "lc3_dec_synth_kernel"): calls[r["Counter_Name"]] += 1
+        if k.startswith("lc3_enc_pack_kernel") or k.startswith("lc3_dec_synth_kernel"): calls[r["Counter_Name"]] += 1
 frames = float("${FRAMES_PER_CALL:-262144}")
 names = sorted({c for _, c in per}); kernels = sorted({k for k, _ in per})
 with open(out + "/summary.txt", "w") as o:
