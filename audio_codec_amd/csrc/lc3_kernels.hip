@@ -47,7 +47,9 @@
 #define MEMCAP LC3D_MEMCAP_STD  /* MDCT overlap memory: N - la_zeros <= 300 for every N <= 480 except 96 kHz / 5 ms */
 #define SMW 548
 #define KERNEL_NAME lc3_encode_kernel
+#ifndef KERNEL_WAVES
 #define KERNEL_WAVES 4
+#endif
 #endif
 #define NQL ((MAXN / 4 + 63) / 64)   /* bisection energies (4 bins each) per lane: 2 or 4 */
 #define WAVE 64
