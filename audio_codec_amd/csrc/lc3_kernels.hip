@@ -2926,7 +2926,7 @@ extern "C" __global__ void lc3_enc_rate_kernel_big(const lc3d_plan* __restrict__
  * that drive two batches never race on them, and a context's behaviour does not change under it. */
 struct lc3hip_opts {
     int fused, no_split, streams5, run_frames, runs, ahead_max, rate_stream /* -1 rule, 0, 1 */, pre_runs, pitch2, scf_wave, front4, shape_fpw, shape_on_s, shape_wave,
-        pack_wpg, pack_stream /* -1 off (default), 0, 1 */, resample48, dec_imdct4, check_ready, tailw_bytes, dec_parse_pad_kb, pack_pad_kb, pack_split, pack_w5;
+        pack_wpg, pack_stream /* -1 off (default), 0, 1 */, resample48, dec_imdct4, check_ready, tailw_bytes, dec_parse_pad_kb, pack_pad_kb, pack_split, pack_w5, fuse_vq;
 };
 static int env_int(const char* name, int lo, int hi, int dflt) { const char* e = getenv(name); if (!e || !*e) return dflt; const int v = atoi(e); return v >= lo && v <= hi ? v : dflt; }
 static void read_opts(lc3hip_opts* o)
@@ -2956,6 +2956,7 @@ static void read_opts(lc3hip_opts* o)
     o->pack_pad_kb = env_int("LC3PLUS_ENC_PACK_PAD_KB", 0, 60, -1);      /* LDS padding per writer workgroup = fewer resident writer waves; -1: the rule in enc_launch */
     o->pack_split = env_int("LC3PLUS_ENC_PACK_SPLIT", 0, 1, -1);        /* the writer as two kernels (head, coder); -1: the rule in enc_launch */
     o->pack_w5 = env_int("LC3PLUS_ENC_PACK_W5", 0, 1, -1);              /* the writer under a 96-register budget; -1: the rule in enc_launch (long calls of small 10 ms frames) */
+    o->fuse_vq = env_int("LC3PLUS_ENC_FUSE_VQ", 0, 1, 0);               /* the SNS quantiser at the tail of the scale-factor kernel where no stream has attack handling */
     o->check_ready = env_int("LC3PLUS_CHECK_READY", 0, 1, 0);        /* debug aid for lc3plus_enc_batch_set_input_ready: refuse a call made while foreign work is pending on the caller's stream */
     o->dec_imdct4 = env_int("LC3PLUS_DEC_IMDCT4", 0, 1, 1);          /* 0 = the one-frame-at-a-time IMDCT for N = 480 too */
 }
@@ -3252,11 +3253,12 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
             else DUPL('f') hipLaunchKernelGGL(lc3_enc_front_kernel, dim3((unsigned)c->ncs * fruns), dim3(WAVE), 0, c->s_fr, c->d_plan, c->d_chans, c->d_state, dpcm, bitdepth, n_frames, tb, nt, fpw, c->ncs, dspec, c->srow, dT, dt0, dfrec, xn_w, xprev, xprev_stride, scf_wave);
             HIPCHK(hipEventRecord(c->ev_m[k], c->s_fr));                 /* the MDCT memory hand-over and the spectrum rows of the run are written */
             if (five) HIPCHK(hipStreamWaitEvent(c->s_ln, c->ev_m[k], 0));
-            if (!scf_wave) DUPL('e') hipLaunchKernelGGL(lc3_enc_scf_lane_kernel, dim3((unsigned)(((long long)c->ncs * nt + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->s_ln, c->d_plan, dT, dt0 + tb, nt, c->ncs, dspec, c->srow, dfrec);
+            const int fuse_vq = !scf_wave && !c->any_attack && c->opt.fuse_vq;
+            if (!scf_wave) DUPL('e') hipLaunchKernelGGL(lc3_enc_scf_lane_kernel, dim3((unsigned)(((long long)c->ncs * nt + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->s_ln, c->d_plan, dT, dt0 + tb, nt, c->ncs, dspec, c->srow, dfrec, fuse_vq);
             if (c->any_attack)
                 hipLaunchKernelGGL(lc3_enc_attack_kernel, dim3((unsigned)((c->ncs + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->s_ln, c->d_plan, c->d_chans, c->d_state, c->state_words, LC3D_ST_SCAL(mc), dfrec, dT, dt0, tb, nt, c->ncs);
             const long long nfr = (long long)c->ncs * nt;
-            DUPL('v') hipLaunchKernelGGL(lc3_enc_snsvq_kernel, dim3((unsigned)((nfr + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->s_ln, c->d_plan, dfrec, dT, dt0, tb, nt, c->ncs, c->any_attack);
+            if (!fuse_vq) DUPL('v') hipLaunchKernelGGL(lc3_enc_snsvq_kernel, dim3((unsigned)((nfr + WAVE - 1) / WAVE)), dim3(WAVE), 0, c->s_ln, c->d_plan, dfrec, dT, dt0, tb, nt, c->ncs, c->any_attack);
             {   /* shaping, TNS and the stateless half of the gain estimate: frame-parallel, behind the quantiser (LC3PLUS_ENC_SHAPE_ON_S=1, diagnostic: on the
                  * launch stream in front of the rate kernel instead) */
                 const int sfpw = c->opt.shape_fpw ? c->opt.shape_fpw : SHAPE_FPW, son = c->opt.shape_on_s;
