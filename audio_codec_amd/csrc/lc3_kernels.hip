@@ -2926,7 +2926,7 @@ extern "C" __global__ void lc3_enc_rate_kernel_big(const lc3d_plan* __restrict__
  * that drive two batches never race on them, and a context's behaviour does not change under it. */
 struct lc3hip_opts {
     int fused, no_split, streams5, run_frames, runs, ahead_max, rate_stream /* -1 rule, 0, 1 */, pre_runs, pitch2, scf_wave, front4, shape_fpw, shape_on_s, shape_wave,
-        pack_wpg, pack_stream /* -1 off (default), 0, 1 */, resample48, dec_imdct4, check_ready, tailw_bytes, dec_parse_pad_kb, pack_pad_kb, pack_split, pack_w5, fuse_vq;
+        pack_wpg, pack_stream /* -1 off (default), 0, 1 */, resample48, dec_imdct4, check_ready, tailw_bytes, dec_parse_pad_kb, pack_pad_kb, pack_split, pack_w5, fuse_vq, stream_order, stream_skip;
 };
 static int env_int(const char* name, int lo, int hi, int dflt) { const char* e = getenv(name); if (!e || !*e) return dflt; const int v = atoi(e); return v >= lo && v <= hi ? v : dflt; }
 static void read_opts(lc3hip_opts* o)
@@ -2957,6 +2957,8 @@ static void read_opts(lc3hip_opts* o)
     o->pack_split = env_int("LC3PLUS_ENC_PACK_SPLIT", 0, 1, -1);        /* the writer as two kernels (head, coder); -1: the rule in enc_launch */
     o->pack_w5 = env_int("LC3PLUS_ENC_PACK_W5", 0, 1, -1);              /* the writer under a 96-register budget; -1: the rule in enc_launch (long calls of small 10 ms frames) */
     o->fuse_vq = env_int("LC3PLUS_ENC_FUSE_VQ", 0, 1, 0);               /* the SNS quantiser at the tail of the scale-factor kernel where no stream has attack handling */
+    o->stream_order = env_int("LC3PLUS_ENC_STREAM_ORDER", 0, 5, -1);    /* creation order of the side streams (HIP maps streams onto its hardware queues in creation order); -1: the rule in enc_launch */
+    o->stream_skip = env_int("LC3PLUS_ENC_STREAM_SKIP", 0, 8, 0);
     o->check_ready = env_int("LC3PLUS_CHECK_READY", 0, 1, 0);        /* debug aid for lc3plus_enc_batch_set_input_ready: refuse a call made while foreign work is pending on the caller's stream */
     o->dec_imdct4 = env_int("LC3PLUS_DEC_IMDCT4", 0, 1, 1);          /* 0 = the one-frame-at-a-time IMDCT for N = 480 too */
 }
@@ -3160,13 +3162,24 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
         if (c->frec_cap[hb_] < nr) { if (c->d_frec[hb_]) HIPCHK(hipFree(c->d_frec[hb_])); c->d_frec[hb_] = nullptr; c->frec_cap[hb_] = 0; HIPCHK(hipMalloc((void**)&c->d_frec[hb_], nr * sizeof(float))); c->frec_cap[hb_] = nr; }
         for (int i = 0; i < LC3D_SETS + 1; i++) if (!c->d_xnext[i]) HIPCHK(hipMalloc((void**)&c->d_xnext[i], (size_t)c->ncs * mc * sizeof(float)));
         if (!c->s_pre) {
-            HIPCHK(hipStreamCreateWithFlags(&c->s_pre, hipStreamNonBlocking)); HIPCHK(hipStreamCreateWithFlags(&c->s_fr, hipStreamNonBlocking));
+            {   /* Which two of the three side streams share a hardware queue.  HIP (four queues by default) gave the FIRST side stream a batch creates a queue of its
+                 * own and put the later ones together on another (timeline of c5: the rate kernels on the front stream's queue, 2.9 of the call's 3.0 ms on that one queue) -
+                 * and kernels of two streams on one queue run one after the other.  The rate stream has to share; the question is with whom.  Measured (Mframes/s,
+                 * pitch stream first / front stream first): 48 kHz / 10 ms x 64 frames at 120 bytes 91.6 / 102.5, 160: 88.5 / 98.0, 240: 82.0 / 88.0, 400: 72.8 / 75.2,
+                 * c5 88.3 / 97.1 (calls of 32: 82.7 / 88.5, of 16: 52.7 / 54.0), c4 118.0 / 120.7, c1 112.8 / 113.6 (no rate stream in use); but c3 92.9 / 89.0 and c96
+                 * 32.8 / 30.8; rate stream first: 78 on c5 and c3.  So: the front stream first, except for the large layout and for short calls of small frames.
+                 * (A deployment with GPU_MAX_HW_QUEUES >= 6 does not have the problem.)  LC3PLUS_ENC_STREAM_ORDER = 0 ... 5 forces an order. */
+                static const unsigned char perm[6][3] = {{0, 1, 2}, {2, 0, 1}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 1, 0}};
+                hipStream_t* which[3] = {&c->s_pre, &c->s_fr, &c->s_rt};
+                const int order = c->opt.stream_order >= 0 ? c->opt.stream_order : (c->big || (c->mean_nbytes < 120 && n_frames <= 32)) ? 0 : 3;
+                for (int i = 0; i < c->opt.stream_skip; i++) { hipStream_t d; HIPCHK(hipStreamCreateWithFlags(&d, hipStreamNonBlocking)); }      /* diagnostic: shifts the assignment (never destroyed) */
+                for (int i = 0; i < 3; i++) HIPCHK(hipStreamCreateWithFlags(which[perm[order][i]], hipStreamNonBlocking));
+            }
             /* LC3PLUS_ENC_STREAMS=5: the pitch kernel and the one-frame-per-lane kernels on streams of their own (pays only where the HIP runtime has
              * hardware queues for them: GPU_MAX_HW_QUEUES >= 6) */
             { c->s_pit = c->s_pre; c->s_ln = c->s_fr;
               if (c->opt.streams5) { HIPCHK(hipStreamCreateWithFlags(&c->s_pit, hipStreamNonBlocking)); HIPCHK(hipStreamCreateWithFlags(&c->s_ln, hipStreamNonBlocking)); } }
             for (int i = 0; i < LC3D_MAX_RUNS; i++) { HIPCHK(hipEventCreateWithFlags(&c->ev_h[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_m[i], hipEventDisableTiming)); }
-            HIPCHK(hipStreamCreateWithFlags(&c->s_rt, hipStreamNonBlocking));      /* with the others: no stream creation inside a later (timed) call */
             for (int i = 0; i < 2; i++) { c->s_pk[i] = NULL; HIPCHK(hipEventCreateWithFlags(&c->ev_pk[i], hipEventDisableTiming)); }
             HIPCHK(hipEventCreateWithFlags(&c->ev_rate, hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
