@@ -2926,7 +2926,7 @@ extern "C" __global__ void lc3_enc_rate_kernel_big(const lc3d_plan* __restrict__
  * that drive two batches never race on them, and a context's behaviour does not change under it. */
 struct lc3hip_opts {
     int fused, no_split, streams5, run_frames, runs, ahead_max, rate_stream /* -1 rule, 0, 1 */, pre_runs, pitch2, scf_wave, front4, shape_fpw, shape_on_s, shape_wave,
-        pack_wpg, pack_stream /* -1 off (default), 0, 1 */, resample48, dec_imdct4, check_ready, tailw_bytes, dec_parse_pad_kb, pack_pad_kb, pack_split, pack_w5, fuse_vq, stream_order, stream_skip;
+        pack_wpg, pack_stream /* -1 off (default), 0, 1 */, resample48, dec_imdct4, check_ready, tailw_bytes, dec_parse_pad_kb, pack_pad_kb, pack_split, pack_w5, fuse_vq, stream_order, stream_skip, rate_on;
 };
 static int env_int(const char* name, int lo, int hi, int dflt) { const char* e = getenv(name); if (!e || !*e) return dflt; const int v = atoi(e); return v >= lo && v <= hi ? v : dflt; }
 static void read_opts(lc3hip_opts* o)
@@ -2957,8 +2957,9 @@ static void read_opts(lc3hip_opts* o)
     o->pack_split = env_int("LC3PLUS_ENC_PACK_SPLIT", 0, 1, -1);        /* the writer as two kernels (head, coder); -1: the rule in enc_launch */
     o->pack_w5 = env_int("LC3PLUS_ENC_PACK_W5", 0, 1, -1);              /* the writer under a 96-register budget; -1: the rule in enc_launch (long calls of small 10 ms frames) */
     o->fuse_vq = env_int("LC3PLUS_ENC_FUSE_VQ", 0, 1, 0);               /* the SNS quantiser at the tail of the scale-factor kernel where no stream has attack handling */
-    o->stream_order = env_int("LC3PLUS_ENC_STREAM_ORDER", 0, 5, -1);    /* creation order of the side streams (HIP maps streams onto its hardware queues in creation order); -1: the rule in enc_launch */
+    o->stream_order = env_int("LC3PLUS_ENC_STREAM_ORDER", 0, 1, 1);     /* diagnostic: 0 = the pitch stream is created before the front stream */
     o->stream_skip = env_int("LC3PLUS_ENC_STREAM_SKIP", 0, 8, 0);
+    o->rate_on = env_int("LC3PLUS_ENC_RATE_ON", 0, 1, -1);                /* a rate chain that leaves the caller's stream runs on the front stream (0) / the pitch stream (1); -1: the rule in enc_launch */
     o->check_ready = env_int("LC3PLUS_CHECK_READY", 0, 1, 0);        /* debug aid for lc3plus_enc_batch_set_input_ready: refuse a call made while foreign work is pending on the caller's stream */
     o->dec_imdct4 = env_int("LC3PLUS_DEC_IMDCT4", 0, 1, 1);          /* 0 = the one-frame-at-a-time IMDCT for N = 480 too */
 }
@@ -2976,7 +2977,7 @@ struct lc3hip_ctx {
     /* host-pointer pipeline (lc3hip_encode_host): two chunk slots, each with device staging and (for pageable callers) pinned staging */
     void* hp_dpcm[2]; void* hp_pin_in[2]; size_t hp_pcm_cap, hp_pin_in_cap;
     hipStream_t s_h2d; hipEvent_t ev_h2d[2], ev_k[2];
-    hipStream_t s_pre, s_fr, s_pit, s_ln, s_rt; hipEvent_t ev_rate; int rate_armed, mean_nbytes, min_nbytes, max_nbytes; int* h_nb; hipEvent_t ev_fork, ev_p[LC3D_MAX_RUNS], ev_f[LC3D_MAX_RUNS], ev_h[LC3D_MAX_RUNS], ev_m[LC3D_MAX_RUNS];   /* side streams: pitch chain, frame-parallel front, frame-parallel tail */
+    hipStream_t s_pre, s_fr, s_pit, s_ln; hipEvent_t ev_rate; int rate_armed, mean_nbytes, min_nbytes, max_nbytes; int* h_nb; hipEvent_t ev_fork, ev_p[LC3D_MAX_RUNS], ev_f[LC3D_MAX_RUNS], ev_h[LC3D_MAX_RUNS], ev_m[LC3D_MAX_RUNS];   /* side streams: pitch chain, frame-parallel front, frame-parallel tail */
     int ylen, srow, la, len12, fm_frames; const float* last_frec; int last_frec_frames;      /* the records of the last pipelined call (lc3hip_last_records) */
     hipStream_t stream, last_stream; hipEvent_t ev0, ev1; float last_ms;
     hipEvent_t ev_ours, ev_now; int ours_armed;       /* LC3PLUS_CHECK_READY: the tail of the library's own work on the caller's stream */
@@ -3162,18 +3163,13 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
         if (c->frec_cap[hb_] < nr) { if (c->d_frec[hb_]) HIPCHK(hipFree(c->d_frec[hb_])); c->d_frec[hb_] = nullptr; c->frec_cap[hb_] = 0; HIPCHK(hipMalloc((void**)&c->d_frec[hb_], nr * sizeof(float))); c->frec_cap[hb_] = nr; }
         for (int i = 0; i < LC3D_SETS + 1; i++) if (!c->d_xnext[i]) HIPCHK(hipMalloc((void**)&c->d_xnext[i], (size_t)c->ncs * mc * sizeof(float)));
         if (!c->s_pre) {
-            {   /* Which two of the three side streams share a hardware queue.  HIP (four queues by default) gave the FIRST side stream a batch creates a queue of its
-                 * own and put the later ones together on another (timeline of c5: the rate kernels on the front stream's queue, 2.9 of the call's 3.0 ms on that one queue) -
-                 * and kernels of two streams on one queue run one after the other.  The rate stream has to share; the question is with whom.  Measured (Mframes/s,
-                 * pitch stream first / front stream first): 48 kHz / 10 ms x 64 frames at 120 bytes 91.6 / 102.5, 160: 88.5 / 98.0, 240: 82.0 / 88.0, 400: 72.8 / 75.2,
-                 * c5 88.3 / 97.1 (calls of 32: 82.7 / 88.5, of 16: 52.7 / 54.0), c4 118.0 / 120.7, c1 112.8 / 113.6 (no rate stream in use); but c3 92.9 / 89.0 and c96
-                 * 32.8 / 30.8; rate stream first: 78 on c5 and c3.  So: the front stream first, except for the large layout and for short calls of small frames.
-                 * (A deployment with GPU_MAX_HW_QUEUES >= 6 does not have the problem.)  LC3PLUS_ENC_STREAM_ORDER = 0 ... 5 forces an order. */
-                static const unsigned char perm[6][3] = {{0, 1, 2}, {2, 0, 1}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 1, 0}};
-                hipStream_t* which[3] = {&c->s_pre, &c->s_fr, &c->s_rt};
-                const int order = c->opt.stream_order >= 0 ? c->opt.stream_order : (c->big || (c->mean_nbytes < 120 && n_frames <= 32)) ? 0 : 3;
+            {   /* Two side streams, no third.  HIP (four hardware queues by default) gave the FIRST side stream a batch creates a queue of its own and put all later ones
+                 * together on another - and kernels of two streams on one queue run one after the other.  Round 3's separate rate stream therefore shared the front stream's
+                 * queue (timeline of c5: 2.9 of the call's 3.0 ms on that one queue).  A rate chain that leaves the caller's stream now runs ON one of the two side streams,
+                 * chosen per call (below): the same packets in the same queue, by choice instead of by creation order. */
                 for (int i = 0; i < c->opt.stream_skip; i++) { hipStream_t d; HIPCHK(hipStreamCreateWithFlags(&d, hipStreamNonBlocking)); }      /* diagnostic: shifts the assignment (never destroyed) */
-                for (int i = 0; i < 3; i++) HIPCHK(hipStreamCreateWithFlags(which[perm[order][i]], hipStreamNonBlocking));
+                if (c->opt.stream_order) { HIPCHK(hipStreamCreateWithFlags(&c->s_fr, hipStreamNonBlocking)); HIPCHK(hipStreamCreateWithFlags(&c->s_pre, hipStreamNonBlocking)); }
+                else { HIPCHK(hipStreamCreateWithFlags(&c->s_pre, hipStreamNonBlocking)); HIPCHK(hipStreamCreateWithFlags(&c->s_fr, hipStreamNonBlocking)); }
             }
             /* LC3PLUS_ENC_STREAMS=5: the pitch kernel and the one-frame-per-lane kernels on streams of their own (pays only where the HIP runtime has
              * hardware queues for them: GPU_MAX_HW_QUEUES >= 6) */
@@ -3216,13 +3212,17 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
          * process created), and on c4 4 %.  LC3PLUS_ENC_RATE_STREAM=0 / 1 forces the choice (diagnostic). */
         const int rt_env = c->opt.rate_stream;
         const bool want_rt = rt_env == 1 || (rt_env < 0 && (c->mean_nbytes >= 120 || n_frames <= 32));
-        hipStream_t rts = want_rt ? c->s_rt : NULL;          /* NULL: the rate kernels run on the caller's stream */
+        /* ... and then on which side stream: behind the pitch kernel (it waits for the shape kernel's event) or behind the shape kernel (it waits for the pitch kernel's).
+         * Measured (Mframes/s, front stream / pitch stream): 48 kHz / 10 ms x 64 frames at 120 bytes 91.6 / 102.5, 160: 88.5 / 98.0, 240: 82.0 / 88.0, 400: 72.8 / 75.2, c5 88.3 / 97.1 (calls of
+         * 32: 82.7 / 88.5); 80-byte frames in calls of 6: 51.3 / 60.4, 8: 62.3 / 68.1, 12: 72.4 / 88.6, 14: 80.6 / 88.4, 18: 85.3 / 90.8, 28: 93.4 / 95.5, 32: 94.6 / 100.9 - but of 16: 94.2 / 92.6 (c3 94.1 / 89.8),
+         * 20: 93.8 / 91.0, 24: 96.4 / 92.9, and c96 32.8 / 30.8.  The pitch stream is the lighter one; behind the shape kernel the rate kernel blocks nothing while it waits, which wins where the
+         * front stream is at its best (calls of 16 ... 24 frames in whole groups of four - lc3_enc_front4_kernel's unit) and in the large layout. */
+        const bool on_pre = c->opt.rate_on >= 0 ? c->opt.rate_on == 1 : !(c->big || (c->mean_nbytes < 120 && n_frames >= 16 && n_frames <= 24 && (n_frames & 3) == 0));
+        hipStream_t rts = want_rt ? (on_pre ? c->s_pit : c->s_ln) : NULL;          /* NULL: the rate kernels run on the caller's stream */
         if (!ahead) {
             HIPCHK(hipEventRecord(c->ev_fork, s)); HIPCHK(hipStreamWaitEvent(c->s_pre, c->ev_fork, 0)); HIPCHK(hipStreamWaitEvent(c->s_fr, c->ev_fork, 0));
             if (five) { HIPCHK(hipStreamWaitEvent(c->s_pit, c->ev_fork, 0)); HIPCHK(hipStreamWaitEvent(c->s_ln, c->ev_fork, 0)); }
-            if (rts) HIPCHK(hipStreamWaitEvent(rts, c->ev_fork, 0));
         } else {
-            if (rts) HIPCHK(hipStreamWaitEvent(rts, c->ev_done[hb_], 0));       /* the records the rate kernel writes were last read by that writer */
             HIPCHK(hipStreamWaitEvent(c->s_pre, c->ev_m[R - 1], 0));    /* the resampler reads the hand-over the previous call's last front kernel wrote */
             HIPCHK(hipStreamWaitEvent(c->s_pre, c->ev_done[hb_], 0)); HIPCHK(hipStreamWaitEvent(c->s_fr, c->ev_done[hb_], 0));
             if (five) { HIPCHK(hipStreamWaitEvent(c->s_pit, c->ev_done[hb_], 0)); HIPCHK(hipStreamWaitEvent(c->s_ln, c->ev_done[hb_], 0));
@@ -3234,7 +3234,6 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
          * streams than these two do not help: HIP multiplexes streams onto a few hardware queues and kernels of two streams that share
          * one run back to back.) */
         hipStream_t rs = s;                                  /* where the rate kernels run */
-        if (c->rate_armed) { HIPCHK(hipStreamWaitEvent(rts ? rts : s, c->ev_rate, 0)); }      /* the rate chain is a chain: behind the previous call's, whichever stream that ran on */
         for (int k = 0, tb = 0, hb = 0, hk = 0; tb < n_frames; k++, tb += Tr) {
             const int nt = n_frames - tb < Tr ? n_frames - tb : Tr;
             if (tb >= hb) {
@@ -3288,6 +3287,7 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
                 if (!son) { HIPCHK(hipEventRecord(c->ev_f[k], c->s_ln)); HIPCHK(hipStreamWaitEvent(rs, c->ev_f[k], 0)); }
             }
             HIPCHK(hipStreamWaitEvent(rs, c->ev_p[k], 0));
+            if (k == 0 && c->rate_armed) HIPCHK(hipStreamWaitEvent(rs, c->ev_rate, 0));      /* the rate chain is a chain: behind the previous call's, whichever stream that ran on */
             const int last = tb + nt >= n_frames;            /* behind the last frame of this launch the MDCT memory goes into the state */
             if (c->big) hipLaunchKernelGGL(lc3_enc_rate_kernel_big, dim3((unsigned)((c->ncs + RATE_WG - 1) / RATE_WG)), dim3(RATE_WG * WAVE), 0, rs, c->d_plan, c->d_chans, c->d_state, dT, dt0 + tb, nt, c->ncs, dspec, c->srow, dfrec, xn_w, last);
             else DUPL('s') hipLaunchKernelGGL(lc3_enc_rate_kernel, dim3((unsigned)((c->ncs + RATE_WG - 1) / RATE_WG)), dim3(RATE_WG * WAVE), 0, rs, c->d_plan, c->d_chans, c->d_state, dT, dt0 + tb, nt, c->ncs, dspec, c->srow, dfrec, xn_w, last);
@@ -3556,7 +3556,7 @@ extern "C" int lc3hip_destroy(void* ctx)
         if (c->ev_k[i]) hipEventDestroy(c->ev_k[i]);
     }
     if (c->s_h2d) hipStreamDestroy(c->s_h2d);
-    if (c->s_pre) { if (c->s_pit != c->s_pre) { hipStreamDestroy(c->s_pit); hipStreamDestroy(c->s_ln); } hipStreamDestroy(c->s_pre); hipStreamDestroy(c->s_fr); if (c->s_rt) hipStreamDestroy(c->s_rt); for (int i = 0; i < 2; i++) { if (c->s_pk[i]) hipStreamDestroy(c->s_pk[i]); hipEventDestroy(c->ev_pk[i]); } hipEventDestroy(c->ev_rate);
+    if (c->s_pre) { if (c->s_pit != c->s_pre) { hipStreamDestroy(c->s_pit); hipStreamDestroy(c->s_ln); } hipStreamDestroy(c->s_pre); hipStreamDestroy(c->s_fr); for (int i = 0; i < 2; i++) { if (c->s_pk[i]) hipStreamDestroy(c->s_pk[i]); hipEventDestroy(c->ev_pk[i]); } hipEventDestroy(c->ev_rate);
                     for (int i = 0; i < LC3D_MAX_RUNS; i++) { hipEventDestroy(c->ev_h[i]); hipEventDestroy(c->ev_m[i]); } hipEventDestroy(c->ev_fork); for (int i = 0; i < LC3D_SETS; i++) hipEventDestroy(c->ev_done[i]);
                     for (int i = 0; i < LC3D_MAX_RUNS; i++) { hipEventDestroy(c->ev_p[i]); hipEventDestroy(c->ev_f[i]); } }
     if (c->ev0) hipEventDestroy(c->ev0);
