@@ -2926,7 +2926,7 @@ extern "C" __global__ void lc3_enc_rate_kernel_big(const lc3d_plan* __restrict__
  * that drive two batches never race on them, and a context's behaviour does not change under it. */
 struct lc3hip_opts {
     int fused, no_split, streams5, run_frames, runs, ahead_max, rate_stream /* -1 rule, 0, 1 */, pre_runs, pitch2, scf_wave, front4, shape_fpw, shape_on_s, shape_wave,
-        pack_wpg, pack_stream /* -1 off (default), 0, 1 */, resample48, dec_imdct4, check_ready, tailw_bytes, dec_parse_pad_kb, pack_pad_kb, pack_split, pack_w5, fuse_vq, stream_order, stream_skip, rate_on;
+        pack_wpg, pack_stream /* -1 off (default), 0, 1 */, resample48, dec_imdct4, check_ready, tailw_bytes, dec_parse_pad_kb, pack_pad_kb, pack_split, pack_w5, fuse_vq, stream_order, stream_skip, rate_on, dec_plc_stream;
 };
 static int env_int(const char* name, int lo, int hi, int dflt) { const char* e = getenv(name); if (!e || !*e) return dflt; const int v = atoi(e); return v >= lo && v <= hi ? v : dflt; }
 static void read_opts(lc3hip_opts* o)
@@ -2960,6 +2960,7 @@ static void read_opts(lc3hip_opts* o)
     o->stream_order = env_int("LC3PLUS_ENC_STREAM_ORDER", 0, 1, 1);     /* diagnostic: 0 = the pitch stream is created before the front stream */
     o->stream_skip = env_int("LC3PLUS_ENC_STREAM_SKIP", 0, 8, 0);
     o->rate_on = env_int("LC3PLUS_ENC_RATE_ON", 0, 1, -1);                /* a rate chain that leaves the caller's stream runs on the front stream (0) / the pitch stream (1); -1: the rule in enc_launch */
+    o->dec_plc_stream = env_int("LC3PLUS_DEC_PLC_STREAM", 0, 1, 1);        /* 0 = the decoder's concealment bookkeeping on the caller's stream (round 3) */
     o->check_ready = env_int("LC3PLUS_CHECK_READY", 0, 1, 0);        /* debug aid for lc3plus_enc_batch_set_input_ready: refuse a call made while foreign work is pending on the caller's stream */
     o->dec_imdct4 = env_int("LC3PLUS_DEC_IMDCT4", 0, 1, 1);          /* 0 = the one-frame-at-a-time IMDCT for N = 480 too */
 }
@@ -3572,6 +3573,9 @@ extern "C" __global__ void lc3_dec_imdct_kernel_big(const lc3d_plan* __restrict_
 extern "C" __global__ void lc3_dec_synth_kernel_big(const lc3d_plan* __restrict__ P, const lc3d_dchan* __restrict__ chans, float* __restrict__ state, const int* __restrict__ rec,
                                                     const float* __restrict__ ws, const float* __restrict__ ov, int T, void* __restrict__ pcm, int bps, int ncs,
                                                     uint8_t* __restrict__ status, lc3d_dec_trace* __restrict__ trace);
+#ifndef DEC_SETS
+#define DEC_SETS 3                      /* sets of hand-over buffers (records, spectrum rows) under the decoder's input-ready promise: the parser of call k + 2 may write while call k is synthesised */
+#endif
 struct lc3hip_dctx {
     lc3hip_opts opt;
     int device, ncs, n_streams, channels, N, big;
@@ -3582,7 +3586,7 @@ struct lc3hip_dctx {
     hipStream_t stream, last_stream; hipEvent_t ev0, ev1; float last_ms;
     /* lc3hip_dec_set_input_ready: the parse kernel of a call runs on a stream of its own beside the transform and synthesis of the call before; a
      * second set of hand-over buffers (records, spectrum rows), alternating */
-    int input_ready, set; int* d_rec2; float* d_ws2; size_t hand2_cap; hipStream_t s_par; hipEvent_t ev_par[2], ev_free[2]; int free_armed[2];
+    int input_ready, set; int* d_recx[DEC_SETS - 1]; float* d_wsx[DEC_SETS - 1]; size_t handx_cap; hipStream_t s_par, s_plc; hipEvent_t ev_par[DEC_SETS], ev_free[DEC_SETS], ev_plc; int free_armed[DEC_SETS];
 };
 extern "C" int lc3hip_dec_destroy(void* ctx);
 extern "C" int lc3hip_dec_create(void** out_ctx, const lc3d_plan* plan, int n_streams, int device)
@@ -3689,18 +3693,24 @@ extern "C" int lc3hip_dec_decode(void* ctx, const void* frames, int frames_on_de
         const size_t cf = (size_t)c->ncs * n_frames;
         if (!c->s_par) {
             HIPCHK(hipStreamCreateWithFlags(&c->s_par, hipStreamNonBlocking));
-            for (int i = 0; i < 2; i++) { HIPCHK(hipEventCreateWithFlags(&c->ev_par[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_free[i], hipEventDisableTiming)); }
+            for (int i = 0; i < DEC_SETS; i++) { HIPCHK(hipEventCreateWithFlags(&c->ev_par[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_free[i], hipEventDisableTiming)); }
+            HIPCHK(hipStreamCreateWithFlags(&c->s_plc, hipStreamNonBlocking)); HIPCHK(hipEventCreateWithFlags(&c->ev_plc, hipEventDisableTiming));
         }
-        if (c->hand2_cap < cf) {
+        if (c->handx_cap < cf) {
             HIPCHK(hipDeviceSynchronize());
-            if (c->d_rec2) HIPCHK(hipFree(c->d_rec2));
-            if (c->d_ws2) HIPCHK(hipFree(c->d_ws2));
-            c->d_rec2 = nullptr; c->d_ws2 = nullptr; c->hand2_cap = 0;
-            HIPCHK(hipMalloc((void**)&c->d_rec2, cf * PR_WORDS * sizeof(int)));
-            HIPCHK(hipMalloc((void**)&c->d_ws2, cf * WS_ROW(c->N) * sizeof(float)));
-            c->hand2_cap = cf;
+            for (int i = 0; i < DEC_SETS - 1; i++) {
+                if (c->d_recx[i]) HIPCHK(hipFree(c->d_recx[i]));
+                if (c->d_wsx[i]) HIPCHK(hipFree(c->d_wsx[i]));
+                c->d_recx[i] = nullptr; c->d_wsx[i] = nullptr;
+            }
+            c->handx_cap = 0;
+            for (int i = 0; i < DEC_SETS - 1; i++) {
+                HIPCHK(hipMalloc((void**)&c->d_recx[i], cf * PR_WORDS * sizeof(int)));
+                HIPCHK(hipMalloc((void**)&c->d_wsx[i], cf * WS_ROW(c->N) * sizeof(float)));
+            }
+            c->handx_cap = cf;
         }
-        if (c->set) { rec_w = c->d_rec2; ws_w = c->d_ws2; }
+        if (c->set) { rec_w = c->d_recx[c->set - 1]; ws_w = c->d_wsx[c->set - 1]; }
     }
     hipStream_t sp = ahead ? c->s_par : s;
     /* frames of up to 128 bytes are staged in LDS; larger ones would cut the waves per workgroup and are read from global memory */
@@ -3714,7 +3724,7 @@ extern "C" int lc3hip_dec_decode(void* ctx, const void* frames, int frames_on_de
     HIPCHK(hipEventRecord(c->ev0, s));
     /* parse: one stream-frame per lane; concealment bookkeeping: one channel-stream per lane; IMDCT: one channel-frame per wave;
      * synthesis: one channel-stream per wave (lc3_dec_kernels.inc) */
-    if (ahead && c->free_armed[c->set]) HIPCHK(hipStreamWaitEvent(sp, c->ev_free[c->set], 0));      /* this set was last read by the synthesis of the call before the previous one */
+    if (ahead && c->free_armed[c->set]) HIPCHK(hipStreamWaitEvent(sp, c->ev_free[c->set], 0));      /* this set was last read by the synthesis of the call DEC_SETS back */
     /* How many parse waves a CU holds.  The kernel for frames of more than 128 bytes reads its frames from global memory and needs little LDS, so its 4 096
      * waves of 128 registers fill every SIMD, and the 64-wave concealment kernel and the transform of the call before wait for parse waves to retire; 24 KB of
      * padding per workgroup leave room beside them: d5 81.3 -> 88.7 Mframes/s (20 KB: 87.1, 28 KB: 77.1).  The kernel that stages its frames in LDS (d1) loses
@@ -3725,9 +3735,19 @@ extern "C" int lc3hip_dec_decode(void* ctx, const void* frames, int frames_on_de
     else hipLaunchKernelGGL(lc3_dec_parse_kernel_g, dim3((unsigned)((tasks + per_wg - 1) / per_wg)), dim3(wpg * WAVE), per_wave * wpg + pad, sp, c->d_plan, c->d_chans, din, in_stride,
                             dbfi, n_frames, c->n_streams, nw_max, rec_w, ws_w, WS_ROW(c->N));
     HIPCHK(hipGetLastError());
-    if (ahead) { HIPCHK(hipEventRecord(c->ev_par[c->set], sp)); HIPCHK(hipStreamWaitEvent(s, c->ev_par[c->set], 0)); }
-    hipLaunchKernelGGL(lc3_dec_plc_kernel, dim3((unsigned)((c->ncs + WAVE - 1) / WAVE)), dim3(WAVE), 0, s, c->d_plan, c->d_state, rec_w, n_frames, c->ncs);
+    /* The concealment bookkeeping needs its call's parser and the bookkeeping of the call before - NOT the transform or the synthesis of the call before.  On the caller's stream it
+     * became runnable at the moment the NEXT call's parser did (both behind the previous synthesis; the parser waits for its set of hand-over buffers), lost the race for the SIMDs to
+     * 4 096 parse waves of 128 registers, and took 0.9 ms for 0.05 ms of work - on the stream that bounds the call (timeline in profiles/experiments/r04_what_bounds.md, section 8).
+     * On a stream of its own it runs the moment its parser ends, while the chip has room. */
+    hipStream_t spl = s;
+    if (ahead && c->opt.dec_plc_stream) {
+        spl = c->s_plc;
+        HIPCHK(hipEventRecord(c->ev_par[c->set], sp)); HIPCHK(hipStreamWaitEvent(spl, c->ev_par[c->set], 0));
+    } else if (ahead) { HIPCHK(hipEventRecord(c->ev_par[c->set], sp)); HIPCHK(hipStreamWaitEvent(s, c->ev_par[c->set], 0)); }
+    else if (c->s_plc) HIPCHK(hipStreamWaitEvent(s, c->ev_plc, 0));      /* an ordered call behind ahead calls: the bookkeeping is a chain (the event of the last one, if any: waiting on a fresh event is a no-op) */
+    hipLaunchKernelGGL(lc3_dec_plc_kernel, dim3((unsigned)((c->ncs + WAVE - 1) / WAVE)), dim3(WAVE), 0, spl, c->d_plan, c->d_state, rec_w, n_frames, c->ncs);
     HIPCHK(hipGetLastError());
+    if (spl != s) { HIPCHK(hipEventRecord(c->ev_plc, spl)); HIPCHK(hipStreamWaitEvent(s, c->ev_plc, 0)); }
     const unsigned ncf = (unsigned)((size_t)c->ncs * ((n_frames + IMDCT_FPW - 1) / IMDCT_FPW));     /* runs of IMDCT_FPW frames */
     if (c->big) {
         hipLaunchKernelGGL(lc3_dec_imdct_kernel_big, dim3(ncf), dim3(WAVE), 0, s, c->d_plan, c->d_state, rec_w, ws_w, n_frames, c->ncs, c->d_ov, dtr);
@@ -3741,7 +3761,7 @@ extern "C" int lc3hip_dec_decode(void* ctx, const void* frames, int frames_on_de
         hipLaunchKernelGGL(lc3_dec_synth_kernel, dim3(c->ncs), dim3(WAVE), 0, s, c->d_plan, c->d_chans, c->d_state, rec_w, ws_w, c->d_ov, n_frames, dpcm, bps, c->ncs, dst, dtr);
     }
     HIPCHK(hipGetLastError());
-    if (ahead) { HIPCHK(hipEventRecord(c->ev_free[c->set], s)); c->free_armed[c->set] = 1; c->set ^= 1; }
+    if (ahead) { HIPCHK(hipEventRecord(c->ev_free[c->set], s)); c->free_armed[c->set] = 1; c->set = (c->set + 1) % DEC_SETS; }
     else if (c->s_par) { HIPCHK(hipEventRecord(c->ev_free[0], s)); c->free_armed[0] = 1; }      /* an ordered call reads the first set: a later parse-ahead into it waits for this one */
     c->last_stream = s;
     HIPCHK(hipEventRecord(c->ev1, s));
@@ -3790,8 +3810,9 @@ extern "C" int lc3hip_dec_destroy(void* ctx)
     if (!c) return 0;
     hipSetDevice(c->device);
     hipDeviceSynchronize();
-    void* bufs[] = {c->d_plan, c->d_chans, c->d_state, c->d_in, c->d_pcm, c->d_bfi, c->d_trace, c->d_status, c->d_rec, c->d_ws, c->d_ov, c->d_rec2, c->d_ws2};
-    if (c->s_par) { hipStreamDestroy(c->s_par); for (int i = 0; i < 2; i++) { hipEventDestroy(c->ev_par[i]); hipEventDestroy(c->ev_free[i]); } }
+    void* bufs[] = {c->d_plan, c->d_chans, c->d_state, c->d_in, c->d_pcm, c->d_bfi, c->d_trace, c->d_status, c->d_rec, c->d_ws, c->d_ov};
+    for (int i = 0; i < DEC_SETS - 1; i++) { if (c->d_recx[i]) hipFree(c->d_recx[i]); if (c->d_wsx[i]) hipFree(c->d_wsx[i]); }
+    if (c->s_par) { hipStreamDestroy(c->s_par); for (int i = 0; i < DEC_SETS; i++) { hipEventDestroy(c->ev_par[i]); hipEventDestroy(c->ev_free[i]); } hipStreamDestroy(c->s_plc); hipEventDestroy(c->ev_plc); }
     for (void* p : bufs) if (p) hipFree(p);
     if (c->stream) hipStreamDestroy(c->stream);
     if (c->ev0) hipEventDestroy(c->ev0);
