@@ -2926,7 +2926,7 @@ extern "C" __global__ void lc3_enc_rate_kernel_big(const lc3d_plan* __restrict__
  * that drive two batches never race on them, and a context's behaviour does not change under it. */
 struct lc3hip_opts {
     int fused, no_split, streams5, run_frames, runs, ahead_max, rate_stream /* -1 rule, 0, 1 */, pre_runs, pitch2, scf_wave, front4, shape_fpw, shape_on_s, shape_wave,
-        pack_wpg, pack_stream /* -1 off (default), 0, 1 */, resample48, dec_imdct4, check_ready, tailw_bytes, dec_parse_pad_kb, pack_pad_kb, pack_split, pack_w5, fuse_vq, stream_order, stream_skip, rate_on, dec_plc_stream;
+        pack_wpg, pack_stream /* -1 off (default), 0, 1 */, resample48, dec_imdct4, check_ready, tailw_bytes, dec_parse_pad_kb, pack_pad_kb, pack_split, pack_w5, fuse_vq, stream_order, stream_skip, rate_on, dec_plc_stream, shape_on_pitch;
 };
 static int env_int(const char* name, int lo, int hi, int dflt) { const char* e = getenv(name); if (!e || !*e) return dflt; const int v = atoi(e); return v >= lo && v <= hi ? v : dflt; }
 static void read_opts(lc3hip_opts* o)
@@ -2961,6 +2961,7 @@ static void read_opts(lc3hip_opts* o)
     o->stream_skip = env_int("LC3PLUS_ENC_STREAM_SKIP", 0, 8, 0);
     o->rate_on = env_int("LC3PLUS_ENC_RATE_ON", 0, 1, -1);                /* a rate chain that leaves the caller's stream runs on the front stream (0) / the pitch stream (1); -1: the rule in enc_launch */
     o->dec_plc_stream = env_int("LC3PLUS_DEC_PLC_STREAM", 0, 1, 1);        /* 0 = the decoder's concealment bookkeeping on the caller's stream (round 3) */
+    o->shape_on_pitch = env_int("LC3PLUS_ENC_SHAPE_ON_PITCH", 0, 1, 0);   /* diagnostic: the shape kernel on the pitch stream (enc_launch) */
     o->check_ready = env_int("LC3PLUS_CHECK_READY", 0, 1, 0);        /* debug aid for lc3plus_enc_batch_set_input_ready: refuse a call made while foreign work is pending on the caller's stream */
     o->dec_imdct4 = env_int("LC3PLUS_DEC_IMDCT4", 0, 1, 1);          /* 0 = the one-frame-at-a-time IMDCT for N = 480 too */
 }
@@ -2978,7 +2979,7 @@ struct lc3hip_ctx {
     /* host-pointer pipeline (lc3hip_encode_host): two chunk slots, each with device staging and (for pageable callers) pinned staging */
     void* hp_dpcm[2]; void* hp_pin_in[2]; size_t hp_pcm_cap, hp_pin_in_cap;
     hipStream_t s_h2d; hipEvent_t ev_h2d[2], ev_k[2];
-    hipStream_t s_pre, s_fr, s_pit, s_ln; hipEvent_t ev_rate; int rate_armed, mean_nbytes, min_nbytes, max_nbytes; int* h_nb; hipEvent_t ev_fork, ev_p[LC3D_MAX_RUNS], ev_f[LC3D_MAX_RUNS], ev_h[LC3D_MAX_RUNS], ev_m[LC3D_MAX_RUNS];   /* side streams: pitch chain, frame-parallel front, frame-parallel tail */
+    hipStream_t s_pre, s_fr, s_pit, s_ln; hipEvent_t ev_rate; int rate_armed, mean_nbytes, min_nbytes, max_nbytes; int* h_nb; hipEvent_t ev_fork, ev_p[LC3D_MAX_RUNS], ev_f[LC3D_MAX_RUNS], ev_h[LC3D_MAX_RUNS], ev_m[LC3D_MAX_RUNS], ev_v[LC3D_MAX_RUNS];   /* side streams: pitch chain, frame-parallel front, frame-parallel tail */
     int ylen, srow, la, len12, fm_frames; const float* last_frec; int last_frec_frames;      /* the records of the last pipelined call (lc3hip_last_records) */
     hipStream_t stream, last_stream; hipEvent_t ev0, ev1; float last_ms;
     hipEvent_t ev_ours, ev_now; int ours_armed;       /* LC3PLUS_CHECK_READY: the tail of the library's own work on the caller's stream */
@@ -3176,7 +3177,7 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
              * hardware queues for them: GPU_MAX_HW_QUEUES >= 6) */
             { c->s_pit = c->s_pre; c->s_ln = c->s_fr;
               if (c->opt.streams5) { HIPCHK(hipStreamCreateWithFlags(&c->s_pit, hipStreamNonBlocking)); HIPCHK(hipStreamCreateWithFlags(&c->s_ln, hipStreamNonBlocking)); } }
-            for (int i = 0; i < LC3D_MAX_RUNS; i++) { HIPCHK(hipEventCreateWithFlags(&c->ev_h[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_m[i], hipEventDisableTiming)); }
+            for (int i = 0; i < LC3D_MAX_RUNS; i++) { HIPCHK(hipEventCreateWithFlags(&c->ev_h[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_m[i], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_v[i], hipEventDisableTiming)); }
             for (int i = 0; i < 2; i++) { c->s_pk[i] = NULL; HIPCHK(hipEventCreateWithFlags(&c->ev_pk[i], hipEventDisableTiming)); }
             HIPCHK(hipEventCreateWithFlags(&c->ev_rate, hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
@@ -3212,7 +3213,7 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
          * calls of 64 (c1) a fourth side stream costs 0 ... 11 % (it shares one of HIP's four hardware queues with another, depending on what else the
          * process created), and on c4 4 %.  LC3PLUS_ENC_RATE_STREAM=0 / 1 forces the choice (diagnostic). */
         const int rt_env = c->opt.rate_stream;
-        const bool want_rt = rt_env == 1 || (rt_env < 0 && (c->mean_nbytes >= 120 || n_frames <= 32));
+        const bool want_rt = rt_env == 1 || (rt_env < 0 && !c->big && (c->mean_nbytes >= 120 || n_frames <= 32));      /* large layout (c96, with round 4's writer): 36.6 on the caller's stream against 33.9 / 34.5 on the front / pitch stream */
         /* ... and then on which side stream: behind the pitch kernel (it waits for the shape kernel's event) or behind the shape kernel (it waits for the pitch kernel's).
          * Measured (Mframes/s, front stream / pitch stream): 48 kHz / 10 ms x 64 frames at 120 bytes 91.6 / 102.5, 160: 88.5 / 98.0, 240: 82.0 / 88.0, 400: 72.8 / 75.2, c5 88.3 / 97.1 (calls of
          * 32: 82.7 / 88.5); 80-byte frames in calls of 6: 51.3 / 60.4, 8: 62.3 / 68.1, 12: 72.4 / 88.6, 14: 80.6 / 88.4, 18: 85.3 / 90.8, 28: 93.4 / 95.5, 32: 94.6 / 100.9 - but of 16: 94.2 / 92.6 (c3 94.1 / 89.8),
@@ -3277,15 +3278,20 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
                 const int sfpw = c->opt.shape_fpw ? c->opt.shape_fpw : SHAPE_FPW, son = c->opt.shape_on_s;
                 const int spw = nt < sfpw ? nt : sfpw;
                 const unsigned sruns = (unsigned)((nt + spw - 1) / spw);
-                hipStream_t ss = son ? s : c->s_ln;
+                /* LC3PLUS_ENC_SHAPE_ON_PITCH=1 (diagnostic): the shape kernel on the pitch stream, behind the pitch kernel, waiting for the quantiser's event.  Tried for c96, whose
+                 * front stream is the longest (3.6 of a 3.6 ms call) and whose pitch stream the lightest (1.4): the next call's pitch chain then queues behind a shape kernel that
+                 * waits for the front stream - 37.3 -> 31.0 Mframes/s; c1 111 -> 101, c5 97 -> 81, c3 93 -> 83; only c4 gains (122.0 -> 126.1).  Off. */
+                const bool sop = !son && c->opt.shape_on_pitch == 1;
+                hipStream_t ss = son ? s : sop ? c->s_pit : c->s_ln;
                 rs = (son || !rts) ? s : rts;
                 if (son) { HIPCHK(hipEventRecord(c->ev_f[k], c->s_ln)); HIPCHK(hipStreamWaitEvent(s, c->ev_f[k], 0)); }
+                if (sop) { HIPCHK(hipEventRecord(c->ev_v[k], c->s_ln)); HIPCHK(hipStreamWaitEvent(ss, c->ev_v[k], 0)); }
                 const int swave = c->opt.shape_wave;
                 if (!swave) DUPL('a') hipLaunchKernelGGL(lc3_enc_shape_lane_kernel, dim3((unsigned)(((long long)c->ncs * nt + WAVE - 1) / WAVE)), dim3(WAVE), 0, ss, c->d_plan, c->d_chans, dT, dt0 + tb, nt, c->ncs, dspec, c->srow, dfrec);
                 else if (c->big) hipLaunchKernelGGL(lc3_enc_shape_kernel_big, dim3((unsigned)c->ncs * sruns), dim3(WAVE), 0, ss, c->d_plan, c->d_chans, dT, dt0 + tb, nt, spw, c->ncs, dspec, c->srow, dfrec);
                 else DUPL('a') hipLaunchKernelGGL(lc3_enc_shape_kernel, dim3((unsigned)c->ncs * sruns), dim3(WAVE), 0, ss, c->d_plan, c->d_chans, dT, dt0 + tb, nt, spw, c->ncs, dspec, c->srow, dfrec);
                 HIPCHK(hipGetLastError());
-                if (!son) { HIPCHK(hipEventRecord(c->ev_f[k], c->s_ln)); HIPCHK(hipStreamWaitEvent(rs, c->ev_f[k], 0)); }
+                if (!son) { HIPCHK(hipEventRecord(c->ev_f[k], ss)); HIPCHK(hipStreamWaitEvent(rs, c->ev_f[k], 0)); }
             }
             HIPCHK(hipStreamWaitEvent(rs, c->ev_p[k], 0));
             if (k == 0 && c->rate_armed) HIPCHK(hipStreamWaitEvent(rs, c->ev_rate, 0));      /* the rate chain is a chain: behind the previous call's, whichever stream that ran on */
@@ -3558,7 +3564,7 @@ extern "C" int lc3hip_destroy(void* ctx)
     }
     if (c->s_h2d) hipStreamDestroy(c->s_h2d);
     if (c->s_pre) { if (c->s_pit != c->s_pre) { hipStreamDestroy(c->s_pit); hipStreamDestroy(c->s_ln); } hipStreamDestroy(c->s_pre); hipStreamDestroy(c->s_fr); for (int i = 0; i < 2; i++) { if (c->s_pk[i]) hipStreamDestroy(c->s_pk[i]); hipEventDestroy(c->ev_pk[i]); } hipEventDestroy(c->ev_rate);
-                    for (int i = 0; i < LC3D_MAX_RUNS; i++) { hipEventDestroy(c->ev_h[i]); hipEventDestroy(c->ev_m[i]); } hipEventDestroy(c->ev_fork); for (int i = 0; i < LC3D_SETS; i++) hipEventDestroy(c->ev_done[i]);
+                    for (int i = 0; i < LC3D_MAX_RUNS; i++) { hipEventDestroy(c->ev_h[i]); hipEventDestroy(c->ev_m[i]); hipEventDestroy(c->ev_v[i]); } hipEventDestroy(c->ev_fork); for (int i = 0; i < LC3D_SETS; i++) hipEventDestroy(c->ev_done[i]);
                     for (int i = 0; i < LC3D_MAX_RUNS; i++) { hipEventDestroy(c->ev_p[i]); hipEventDestroy(c->ev_f[i]); } }
     if (c->ev0) hipEventDestroy(c->ev0);
     if (c->ev1) hipEventDestroy(c->ev1);
