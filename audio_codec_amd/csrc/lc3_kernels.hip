@@ -2961,7 +2961,7 @@ static void read_opts(lc3hip_opts* o)
     o->stream_skip = env_int("LC3PLUS_ENC_STREAM_SKIP", 0, 8, 0);
     o->rate_on = env_int("LC3PLUS_ENC_RATE_ON", 0, 1, -1);                /* a rate chain that leaves the caller's stream runs on the front stream (0) / the pitch stream (1); -1: the rule in enc_launch */
     o->dec_plc_stream = env_int("LC3PLUS_DEC_PLC_STREAM", 0, 1, 1);        /* 0 = the decoder's concealment bookkeeping on the caller's stream (round 3) */
-    o->shape_on_pitch = env_int("LC3PLUS_ENC_SHAPE_ON_PITCH", 0, 1, 0);   /* diagnostic: the shape kernel on the pitch stream (enc_launch) */
+    o->shape_on_pitch = env_int("LC3PLUS_ENC_SHAPE_ON_PITCH", 0, 1, -1);  /* the shape kernel on the pitch stream; -1: the rule in enc_launch (long calls of 2.5 ms high-resolution frames only) */
     o->check_ready = env_int("LC3PLUS_CHECK_READY", 0, 1, 0);        /* debug aid for lc3plus_enc_batch_set_input_ready: refuse a call made while foreign work is pending on the caller's stream */
     o->dec_imdct4 = env_int("LC3PLUS_DEC_IMDCT4", 0, 1, 1);          /* 0 = the one-frame-at-a-time IMDCT for N = 480 too */
 }
@@ -3280,8 +3280,8 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
                 const unsigned sruns = (unsigned)((nt + spw - 1) / spw);
                 /* LC3PLUS_ENC_SHAPE_ON_PITCH=1 (diagnostic): the shape kernel on the pitch stream, behind the pitch kernel, waiting for the quantiser's event.  Tried for c96, whose
                  * front stream is the longest (3.6 of a 3.6 ms call) and whose pitch stream the lightest (1.4): the next call's pitch chain then queues behind a shape kernel that
-                 * waits for the front stream - 37.3 -> 31.0 Mframes/s; c1 111 -> 101, c5 97 -> 81, c3 93 -> 83; only c4 gains (122.0 -> 126.1).  Off. */
-                const bool sop = !son && c->opt.shape_on_pitch == 1;
+                 * waits for the front stream - 37.3 -> 31.0 Mframes/s; c1 111 -> 101, c5 97 -> 81, c3 93 -> 83; only c4 - long calls of 2.5 ms high-resolution frames, four runs per call, the front stream 8.5 of the 8.6 ms - gains (122.0 -> 126.1): on for that shape only. */
+                const bool sop = !son && (c->opt.shape_on_pitch >= 0 ? c->opt.shape_on_pitch == 1 : (c->hr && c->N == 240 && n_frames >= 128));      /* c4's shape: calls of 128 / 256 frames 123.8 -> 126.0, 122.0 -> 126.1 */
                 hipStream_t ss = son ? s : sop ? c->s_pit : c->s_ln;
                 rs = (son || !rts) ? s : rts;
                 if (son) { HIPCHK(hipEventRecord(c->ev_f[k], c->s_ln)); HIPCHK(hipStreamWaitEvent(s, c->ev_f[k], 0)); }
