@@ -2926,7 +2926,7 @@ extern "C" __global__ void lc3_enc_rate_kernel_big(const lc3d_plan* __restrict__
  * that drive two batches never race on them, and a context's behaviour does not change under it. */
 struct lc3hip_opts {
     int fused, no_split, streams5, run_frames, runs, ahead_max, rate_stream /* -1 rule, 0, 1 */, pre_runs, pitch2, scf_wave, front4, shape_fpw, shape_on_s, shape_wave,
-        pack_wpg, pack_stream /* -1 off (default), 0, 1 */, resample48, dec_imdct4, check_ready, tailw_bytes, dec_parse_pad_kb, pack_pad_kb, pack_split, pack_w5, fuse_vq, stream_order, stream_skip, rate_on, dec_plc_stream, shape_on_pitch;
+        pack_wpg, pack_stream /* -1 off (default), 0, 1 */, resample48, dec_imdct4, check_ready, tailw_bytes, dec_parse_pad_kb, pack_pad_kb, pack_split, pack_w5, fuse_vq, stream_order, stream_skip, rate_on, dec_plc_stream, shape_on_pitch, side_prio;
 };
 static int env_int(const char* name, int lo, int hi, int dflt) { const char* e = getenv(name); if (!e || !*e) return dflt; const int v = atoi(e); return v >= lo && v <= hi ? v : dflt; }
 static void read_opts(lc3hip_opts* o)
@@ -2962,6 +2962,7 @@ static void read_opts(lc3hip_opts* o)
     o->rate_on = env_int("LC3PLUS_ENC_RATE_ON", 0, 1, -1);                /* a rate chain that leaves the caller's stream runs on the front stream (0) / the pitch stream (1); -1: the rule in enc_launch */
     o->dec_plc_stream = env_int("LC3PLUS_DEC_PLC_STREAM", 0, 1, 1);        /* 0 = the decoder's concealment bookkeeping on the caller's stream (round 3) */
     o->shape_on_pitch = env_int("LC3PLUS_ENC_SHAPE_ON_PITCH", 0, 1, -1);  /* the shape kernel on the pitch stream; -1: the rule in enc_launch (long calls of 2.5 ms high-resolution frames only) */
+    o->side_prio = env_int("LC3PLUS_ENC_SIDE_PRIO", 0, 2, 0);             /* diagnostic: 1 = the side streams at the lowest HIP stream priority, 2 = at the highest */
     o->check_ready = env_int("LC3PLUS_CHECK_READY", 0, 1, 0);        /* debug aid for lc3plus_enc_batch_set_input_ready: refuse a call made while foreign work is pending on the caller's stream */
     o->dec_imdct4 = env_int("LC3PLUS_DEC_IMDCT4", 0, 1, 1);          /* 0 = the one-frame-at-a-time IMDCT for N = 480 too */
 }
@@ -3170,8 +3171,10 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
                  * queue (timeline of c5: 2.9 of the call's 3.0 ms on that one queue).  A rate chain that leaves the caller's stream now runs ON one of the two side streams,
                  * chosen per call (below): the same packets in the same queue, by choice instead of by creation order. */
                 for (int i = 0; i < c->opt.stream_skip; i++) { hipStream_t d; HIPCHK(hipStreamCreateWithFlags(&d, hipStreamNonBlocking)); }      /* diagnostic: shifts the assignment (never destroyed) */
-                if (c->opt.stream_order) { HIPCHK(hipStreamCreateWithFlags(&c->s_fr, hipStreamNonBlocking)); HIPCHK(hipStreamCreateWithFlags(&c->s_pre, hipStreamNonBlocking)); }
-                else { HIPCHK(hipStreamCreateWithFlags(&c->s_pre, hipStreamNonBlocking)); HIPCHK(hipStreamCreateWithFlags(&c->s_fr, hipStreamNonBlocking)); }
+                int plo = 0, phi = 0; (void)hipDeviceGetStreamPriorityRange(&plo, &phi);       /* least, greatest */
+                const int prio = c->opt.side_prio == 1 ? plo : c->opt.side_prio == 2 ? phi : 0;
+                if (c->opt.stream_order) { HIPCHK(hipStreamCreateWithPriority(&c->s_fr, hipStreamNonBlocking, prio)); HIPCHK(hipStreamCreateWithPriority(&c->s_pre, hipStreamNonBlocking, prio)); }
+                else { HIPCHK(hipStreamCreateWithPriority(&c->s_pre, hipStreamNonBlocking, prio)); HIPCHK(hipStreamCreateWithPriority(&c->s_fr, hipStreamNonBlocking, prio)); }
             }
             /* LC3PLUS_ENC_STREAMS=5: the pitch kernel and the one-frame-per-lane kernels on streams of their own (pays only where the HIP runtime has
              * hardware queues for them: GPU_MAX_HW_QUEUES >= 6) */
