@@ -832,7 +832,10 @@ def test_odd_stream_counts_and_unaligned_pcm_on_the_pipelined_path(B, T, off):
         d.free()
 
 
-@pytest.mark.parametrize("env", ["LC3PLUS_ENC_FRONT4=0", "LC3PLUS_ENC_PITCH2=0", "LC3PLUS_ENC_RATE_STREAM=1", "LC3PLUS_ENC_PACK_WPG=1", "LC3PLUS_DEC_IMDCT4=0"])
+@pytest.mark.parametrize("env", ["LC3PLUS_ENC_FRONT4=0", "LC3PLUS_ENC_PITCH2=0", "LC3PLUS_ENC_RATE_STREAM=1", "LC3PLUS_ENC_PACK_WPG=1", "LC3PLUS_DEC_IMDCT4=0",
+                                 # round 4's switches: each alternative is byte-identical to the default
+                                 "LC3PLUS_ENC_RESAMPLE48=0", "LC3PLUS_ENC_PACK_W5=1", "LC3PLUS_ENC_PACK_SPLIT=1", "LC3PLUS_ENC_FUSE_VQ=1", "LC3PLUS_ENC_RATE_ON=0",
+                                 "LC3PLUS_ENC_RATE_ON=1", "LC3PLUS_ENC_SHAPE_ON_PITCH=1", "LC3PLUS_ENC_PACK_STREAM=1", "LC3PLUS_DEC_PLC_STREAM=0"])
 def test_diagnostic_switches_give_the_same_bytes(env):
     """The kernels the defaults replaced (one frame at a time front / IMDCT, one stream per wave pitch chain) and the stream / workgroup switches
     still produce the oracle's bytes: a child process per switch (the library reads them once)."""
@@ -857,6 +860,23 @@ def test_diagnostic_switches_give_the_same_bytes(env):
         out, _ = d.decode(got[:, :, :max(nb)].copy())
         ref, _ = oracle_decode_streams(got[:, :, :max(nb)].copy(), nb, None, fs, 10.0, 0, 1)
         assert (out == ref).all()
+        # ... and three overlapped device-pointer calls of 16 frames under the input-ready promise (the stream / writer switches only act there)
+        from test_gpu_parity import _Dev
+        dv = _Dev()
+        T2, K = 16, 3
+        pcm2 = synth_pcm(B, T2 * K, N, fs, seed=100)
+        b2 = audio_codec_amd.Batch(B, fs, 1, 10.0, 0, br, device=0)
+        b2.set_input_ready(True)
+        ins = [dv.put(pcm2[:, k * T2:(k + 1) * T2]) for k in range(K)]
+        outs = [dv.zeros(B * T2 * b2.stride) for _ in range(K)]
+        dv.sync()
+        for k in range(K): b2.encode_device(ins[k], 16, T2, outs[k], b2.stride, hip_stream=None, sync=False)
+        dv.sync()
+        got2 = np.concatenate([dv.get(outs[k], (B, T2, b2.stride), np.uint8) for k in range(K)], axis=1)
+        want2 = _oracle_batch(pcm2, fs, 10.0, 0, br, b2.stride)
+        bad = [(i, t) for i in range(B) for t in range(T2 * K) if (got2[i, t, :nb[i]] != want2[i, t, :nb[i]]).any()]
+        assert not bad, bad[:6]
+        dv.free()
         print("ok")
     """ % (root, os.path.join(root, "tests")))
     k, v = env.split("=")
