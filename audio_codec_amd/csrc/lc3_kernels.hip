@@ -3116,7 +3116,9 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
     if (!in_kernel_writer) {
         dstride = PK_STRIDE(c->N, c->hr);
         const size_t need = (size_t)c->ncs * dT * dstride;
-        if (c->dump_capv[set] < need) { if (c->d_dumpv[set]) HIPCHK(hipFree(c->d_dumpv[set])); c->d_dumpv[set] = nullptr; c->dump_capv[set] = 0; HIPCHK(hipMalloc((void**)&c->d_dumpv[set], need * sizeof(int))); c->dump_capv[set] = need; }
+        /* under the input-ready promise every set is sized on the first call that needs it: no allocation inside a later (timed, overlapped) call */
+        for (int i = c->input_ready ? 0 : set; i < (c->input_ready ? LC3D_SETS : set + 1); i++)
+            if (c->dump_capv[i] < need) { if (c->d_dumpv[i]) HIPCHK(hipFree(c->d_dumpv[i])); c->d_dumpv[i] = nullptr; c->dump_capv[i] = 0; HIPCHK(hipMalloc((void**)&c->d_dumpv[i], need * sizeof(int))); c->dump_capv[i] = need; }
         ddump = c->d_dumpv[set];
     }
     /* ahead of it: the 12.8 kHz resampler of all frames at once and its HP50 recurrence one stream per lane (lc3_enc_pre.inc) */
@@ -3124,13 +3126,15 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
     if (!dtr && !c->fused) {
         const size_t need = (size_t)c->ncs * n_frames * 128;
         const int yb = c->input_ready ? c->row_par : 0;      /* two buffers under the input-ready promise: the next call's resampler may run beside this call's pitch kernel */
-        if (c->y12_cap[yb] < need) { if (c->d_y12[yb]) HIPCHK(hipFree(c->d_y12[yb])); c->d_y12[yb] = nullptr; c->y12_cap[yb] = 0; HIPCHK(hipMalloc((void**)&c->d_y12[yb], need * sizeof(float))); c->y12_cap[yb] = need; }
+        for (int i = c->input_ready ? 0 : yb; i < (c->input_ready ? LC3D_SETS : yb + 1); i++)
+            if (c->y12_cap[i] < need) { if (c->d_y12[i]) HIPCHK(hipFree(c->d_y12[i])); c->d_y12[i] = nullptr; c->y12_cap[i] = 0; HIPCHK(hipMalloc((void**)&c->d_y12[i], need * sizeof(float))); c->y12_cap[i] = need; }
         dy12 = c->d_y12[yb];
     }
     const bool split = dy12 && ddump && !c->opt.no_split;
     if (dt0 == 0) {   /* per channel-frame status bits (LC3D_ENC_ST_*), cleared per call: by the stream that runs the kernel that sets them (the writer's, on the pipelined path) */
         const size_t need = (size_t)c->ncs * dT;
-        if (c->status_capv[set] < need) { if (c->d_statusv[set]) HIPCHK(hipFree(c->d_statusv[set])); c->d_statusv[set] = nullptr; c->status_capv[set] = 0; HIPCHK(hipMalloc((void**)&c->d_statusv[set], need)); c->status_capv[set] = need; }
+        for (int i = c->input_ready ? 0 : set; i < (c->input_ready ? LC3D_SETS : set + 1); i++)
+            if (c->status_capv[i] < need) { if (c->d_statusv[i]) HIPCHK(hipFree(c->d_statusv[i])); c->d_statusv[i] = nullptr; c->status_capv[i] = 0; HIPCHK(hipMalloc((void**)&c->d_statusv[i], need)); c->status_capv[i] = need; }
         c->d_status = c->d_statusv[set];
         if (!split) HIPCHK(hipMemsetAsync(c->d_status, 0, need, s));
         c->status_frames = dT;
@@ -3162,8 +3166,10 @@ static int enc_launch(lc3hip_ctx* c, const void* dpcm, int bitdepth, int n_frame
          * before still reads the other), one otherwise */
         const int hb_ = set;
         const size_t ns = (size_t)c->ncs * dT * c->srow, nr = (size_t)c->ncs * dT * FR_WORDS;
-        if (c->spec_cap[hb_] < ns) { if (c->d_spec[hb_]) HIPCHK(hipFree(c->d_spec[hb_])); c->d_spec[hb_] = nullptr; c->spec_cap[hb_] = 0; HIPCHK(hipMalloc((void**)&c->d_spec[hb_], ns * sizeof(float))); c->spec_cap[hb_] = ns; }
-        if (c->frec_cap[hb_] < nr) { if (c->d_frec[hb_]) HIPCHK(hipFree(c->d_frec[hb_])); c->d_frec[hb_] = nullptr; c->frec_cap[hb_] = 0; HIPCHK(hipMalloc((void**)&c->d_frec[hb_], nr * sizeof(float))); c->frec_cap[hb_] = nr; }
+        for (int i = c->input_ready ? 0 : hb_; i < (c->input_ready ? LC3D_SETS : hb_ + 1); i++) {
+            if (c->spec_cap[i] < ns) { if (c->d_spec[i]) HIPCHK(hipFree(c->d_spec[i])); c->d_spec[i] = nullptr; c->spec_cap[i] = 0; HIPCHK(hipMalloc((void**)&c->d_spec[i], ns * sizeof(float))); c->spec_cap[i] = ns; }
+            if (c->frec_cap[i] < nr) { if (c->d_frec[i]) HIPCHK(hipFree(c->d_frec[i])); c->d_frec[i] = nullptr; c->frec_cap[i] = 0; HIPCHK(hipMalloc((void**)&c->d_frec[i], nr * sizeof(float))); c->frec_cap[i] = nr; }
+        }
         for (int i = 0; i < LC3D_SETS + 1; i++) if (!c->d_xnext[i]) HIPCHK(hipMalloc((void**)&c->d_xnext[i], (size_t)c->ncs * mc * sizeof(float)));
         if (!c->s_pre) {
             {   /* Two side streams, no third.  HIP (four hardware queues by default) gave the FIRST side stream a batch creates a queue of its own and put all later ones
