@@ -363,6 +363,52 @@ def mld_between(frames_a, frames_b, fs, frame_ms, hrmode, channels=1, tmpdir=Non
     return float(m.group(1))
 
 
+RMS_TOOL = os.path.join(ORACLE_DIR, "_ref", "rms")
+RMS_K = 14              # DEFAULTS_TEST['*_rms_threshold'], lc3_conformance.py:129: the comparison is made at 14-bit resolution
+ENG_THRESHOLD = 70      # DEFAULTS_TEST['*_eng_threshold'], lc3_conformance.py:126 (log10 of the summed squared sample difference)
+
+
+def rms_between(frames_a, frames_b, fs, frame_ms, hrmode, channels=1, tmpdir=None, k=RMS_K):
+    """The conformance script's default metric (compare_wav, lc3_conformance.py:610-619) between two bitstreams of one
+    stream, both decoded by the reference decoder: the ETSI `rms` tool per channel at k-bit resolution.  Returns a dict:
+    different samples, the overall RMS in dB and the maximum absolute difference (worst channel), the two thresholds
+    the script derives from k and whether both hold.  Both decodes have the same length and no delay between them, so
+    the script's cross-correlation alignment has nothing to do here."""
+    import math
+    import re
+    import tempfile
+    td = tmpdir or tempfile.mkdtemp(prefix="rms_")
+    pcm = [ref_decode_stream(fr, fs, frame_ms, hrmode, channels) for fr in (frames_a, frames_b)]
+    ndiff, rms, mx = 0, float("-inf"), 0.0
+    for c in range(channels):
+        paths = []
+        for tag, x in zip("ab", pcm):
+            p = os.path.join(str(td), "rms_%s%d.wav" % (tag, c))
+            _write_wav16(p, x[c:c + 1], fs)
+            paths.append(p)
+        out = subprocess.run([RMS_TOOL, paths[0], paths[1], str(k)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True).stdout
+        m = re.search(r"different samples\s+: (\d+)", out)
+        if not m:
+            raise RuntimeError("rms tool output not understood: %r" % out[-400:])
+        if int(m.group(1)):
+            ndiff += int(m.group(1))
+            rms = max(rms, float(re.search(r"Overall RMS value\s+: (\S+) dB ---", out).group(1)))
+            mx = max(mx, float(re.search(r"Maximum difference\s+: (\S+) ---", out).group(1)))
+    rms_thr = 20 * math.log10(2.0 ** (-k + 1) / 12 ** 0.5)
+    diff_thr = 1.0 / 2 ** (k - 3)
+    return {"different_samples": ndiff, "rms_db": rms, "max_abs_diff": mx, "rms_threshold_db": rms_thr, "max_abs_diff_threshold": diff_thr,
+            "ok": rms <= rms_thr and mx <= diff_thr}
+
+
+def energy_diff_between(frames_a, frames_b, fs, frame_ms, hrmode, channels=1):
+    """The script's `eng` metric (energy_diff, lc3_conformance.py:586-600): log10 of the summed squared difference of the two
+    decodes in 16-bit sample units, -inf when they are equal; the gate is <= ENG_THRESHOLD."""
+    import math
+    a, b = (ref_decode_stream(fr, fs, frame_ms, hrmode, channels).astype(np.float64) for fr in (frames_a, frames_b))
+    e = float(((a - b) ** 2).sum())
+    return math.log10(e) if e else float("-inf")
+
+
 def compare_frames(got, want_list, fs, frame_ms, hrmode, channels=1):
     """got [B, T, stride], want_list[b] [T, nbytes_b].  Returns (differing frames, total, worst MLD over the streams that
     differ or None).  The gates assert the first number against the committed count (0); the MLD says whether a

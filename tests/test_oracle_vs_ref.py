@@ -218,3 +218,32 @@ def test_decoder_portable_math_boundary_at_24_bits():
             assert np.abs(a.astype(np.int64) - b).max() <= 1, (fs, ms, t)
             tot += a.size; same += int((a == b).sum())
     assert same > 0.999 * tot, (same, tot)
+
+
+def test_rms_and_energy_metrics_of_the_conformance_procedure():
+    """The conformance script's default metric is not MLD but the ETSI `rms` tool at 14-bit resolution, and its low-pass cases use the
+    energy difference (lc3_conformance.py:126-130, 542-556, 586-619).  oracle/_ref/rms is compiled from the reference's source (oracle/Makefile);
+    this pins the harness around it: equal bitstreams -> no differing sample, -inf energy, gate holds; bitstreams of an input that was
+    moved by one LSB -> the tool's figures parse, the thresholds are the script's (k = 14: -89.06 dB, 2^-11), and a lossy codec's
+    answer to a changed input is correctly NOT inside a 14-bit gate, which is what the soaks would report next to the MLD if a frame ever differed."""
+    import math
+    from lc3_harness import rms_between, energy_diff_between, RMS_TOOL, ENG_THRESHOLD
+    if not os.path.exists(RMS_TOOL):
+        pytest.skip("oracle/_ref/rms not built")
+    fs, ms, T = 48000, 10.0, 24
+    pcm = synth_pcm(2, T, 480, fs, seed=41)
+    pcm2 = pcm.copy(); pcm2[:, :, ::7] += 1
+    pcm2 = np.clip(pcm2.astype(np.int32), -32768, 32767).astype(np.int16)
+    a = oracle_encode_streams(pcm, fs, ms, 0, [64000, 128000])
+    b = oracle_encode_streams(pcm2, fs, ms, 0, [64000, 128000])
+    same = rms_between(a[0], a[0], fs, ms, 0)
+    assert same["different_samples"] == 0 and same["ok"] and same["rms_db"] == float("-inf")
+    assert energy_diff_between(a[0], a[0], fs, ms, 0) == float("-inf")
+    for i in range(2):
+        assert not (a[i] == b[i]).all()
+        r = rms_between(a[i], b[i], fs, ms, 0)
+        assert r["different_samples"] > 0 and math.isfinite(r["rms_db"]) and r["max_abs_diff"] > 0
+        assert abs(r["rms_threshold_db"] - (-89.06)) < 0.01 and r["max_abs_diff_threshold"] == 2.0 ** -11
+        assert not r["ok"]
+        e = energy_diff_between(a[i], b[i], fs, ms, 0)
+        assert 0 < e <= ENG_THRESHOLD

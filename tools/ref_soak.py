@@ -4,7 +4,8 @@ For each BASELINE configuration the same synthetic PCM is encoded by the GPU eng
 (oracle/_ref/cpu_bench_ref = R's own lc3_enc_* API driven from C on all host cores, glibc libm) and the frames are compared byte
 for byte.  Run-time float libm calls are the one place the device cannot be bit-identical to glibc: every
 stream with a differing frame is decoded twice by the reference decoder and the ETSI `mld` tool gives the maximum loudness
-difference, the conformance procedure's measure (threshold 4).  Prints one line per configuration and a JSON summary.
+difference, the conformance procedure's measure (threshold 4), next to the procedure's default metric (the ETSI `rms` tool at 14-bit
+resolution) and its energy difference (lc3_conformance.py:126-130, 542-556, 586-619).  Prints one line per configuration and a JSON summary.
 
 usage: python tools/ref_soak.py [scale]      scale 1.0 = 1.3 M channel-frames in all, 0.02 for the reduced pytest case
 TEST INFRASTRUCTURE (reads oracle/_ref)."""
@@ -12,7 +13,7 @@ import json, os, subprocess, sys, tempfile, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-from lc3_harness import synth_pcm, mld_between, have_ref, MLD_TOOL
+from lc3_harness import synth_pcm, mld_between, rms_between, energy_diff_between, have_ref, MLD_TOOL, RMS_TOOL
 
 REF_BENCH = os.path.join(ROOT, "oracle", "_ref", "cpu_bench_ref")
 RATES12 = [16000, 24000, 32000, 48000, 64000, 80000, 96000, 128000, 160000, 192000, 256000, 320000]
@@ -68,7 +69,7 @@ def run(scale=1.0, verbose=True):
         got = np.concatenate([g1, b.encode(pcm[:, h:] if ch > 1 else pcm[:, h:, 0])], axis=1)   # two calls: state persists
         nbs = [b.num_bytes(i) for i in range(S)]
         b.close()
-        diff = tot = 0; worst = None; nstreams_diff = 0
+        diff = tot = 0; worst = None; nstreams_diff = 0; worst_rms = worst_eng = None; rms_ok = True
         for rate in sorted(set(br)):
             idx = [i for i in range(S) if br[i] == rate]
             nb = nbs[idx[0]]
@@ -81,7 +82,13 @@ def run(scale=1.0, verbose=True):
                 if os.path.exists(MLD_TOOL):
                     v = mld_between(g[k], want[k], fs, ms, hr, ch)
                     worst = v if worst is None else max(worst, v)
-        r = {"config": name, "channel_frames": tot, "frames_differ": diff, "streams_differ": nstreams_diff, "worst_mld": worst}
+                if os.path.exists(RMS_TOOL):            # the script's default metric (rms at 14 bits) and its energy difference, for the record beside the MLD
+                    q = rms_between(g[k], want[k], fs, ms, hr, ch)
+                    worst_rms = q["rms_db"] if worst_rms is None else max(worst_rms, q["rms_db"]); rms_ok = rms_ok and q["ok"]
+                    e = energy_diff_between(g[k], want[k], fs, ms, hr, ch)
+                    worst_eng = e if worst_eng is None else max(worst_eng, e)
+        r = {"config": name, "channel_frames": tot, "frames_differ": diff, "streams_differ": nstreams_diff, "worst_mld": worst,
+             "worst_rms_db": worst_rms, "rms_14bit_ok": rms_ok if worst_rms is not None else None, "worst_energy_diff_log10": worst_eng}
         res.append(r)
         if verbose: print("ref_soak %s: %d channel-frames, %d stream-frames differ in %d streams, worst MLD %s" % (name, tot, diff, nstreams_diff, worst), flush=True)
     return res
