@@ -3744,7 +3744,10 @@ extern "C" int lc3hip_dec_decode(void* ctx, const void* frames, int frames_on_de
      * waves of 128 registers fill every SIMD, and the 64-wave concealment kernel and the transform of the call before wait for parse waves to retire; 24 KB of
      * padding per workgroup leave room beside them: d5 81.3 -> 88.7 Mframes/s (20 KB: 87.1, 28 KB: 77.1).  The kernel that stages its frames in LDS (d1) loses
      * with any padding (129 -> 117 at 16 KB): none there. */
-    const size_t pad = (size_t)(c->opt.dec_parse_pad_kb >= 0 ? c->opt.dec_parse_pad_kb : (nw_max ? 0 : 24)) << 10;
+    /* (the rule in bytes: the workgroup's LDS - tables, its waves' slices, padding - is a quarter of the CU's 160 KB, so that exactly four of them fit; that was 24 KB of padding
+     * with the tables of the time) */
+    const size_t quarter = (160u << 10) / 4, used = sizeof(ParseLds) + per_wave * wpg;
+    const size_t pad = c->opt.dec_parse_pad_kb >= 0 ? (size_t)c->opt.dec_parse_pad_kb << 10 : (nw_max || used >= quarter ? 0 : quarter - used);
     if (nw_max) hipLaunchKernelGGL(lc3_dec_parse_kernel, dim3((unsigned)((tasks + per_wg - 1) / per_wg)), dim3(wpg * WAVE), per_wave * wpg + pad, sp, c->d_plan, c->d_chans, din, in_stride,
                                    dbfi, n_frames, c->n_streams, nw_max, rec_w, ws_w, WS_ROW(c->N));
     else hipLaunchKernelGGL(lc3_dec_parse_kernel_g, dim3((unsigned)((tasks + per_wg - 1) / per_wg)), dim3(wpg * WAVE), per_wave * wpg + pad, sp, c->d_plan, c->d_chans, din, in_stride,
