@@ -2926,7 +2926,7 @@ extern "C" __global__ void lc3_enc_rate_kernel_big(const lc3d_plan* __restrict__
  * that drive two batches never race on them, and a context's behaviour does not change under it. */
 struct lc3hip_opts {
     int fused, no_split, streams5, run_frames, runs, ahead_max, rate_stream /* -1 rule, 0, 1 */, pre_runs, pitch2, scf_wave, front4, shape_fpw, shape_on_s, shape_wave,
-        pack_wpg, pack_stream /* -1 off (default), 0, 1 */, resample48, dec_imdct4, check_ready, tailw_bytes, dec_parse_pad_kb, pack_pad_kb, pack_split, pack_w5, fuse_vq, stream_order, stream_skip, rate_on, dec_plc_stream, shape_on_pitch, side_prio;
+        pack_wpg, pack_stream /* -1 off (default), 0, 1 */, resample48, resample96, dec_imdct4, check_ready, tailw_bytes, dec_parse_pad_kb, pack_pad_kb, pack_split, pack_w5, fuse_vq, stream_order, stream_skip, rate_on, dec_plc_stream, shape_on_pitch, side_prio;
 };
 static int env_int(const char* name, int lo, int hi, int dflt) { const char* e = getenv(name); if (!e || !*e) return dflt; const int v = atoi(e); return v >= lo && v <= hi ? v : dflt; }
 static void read_opts(lc3hip_opts* o)
@@ -2948,6 +2948,7 @@ static void read_opts(lc3hip_opts* o)
     o->pack_wpg = env_int("LC3PLUS_ENC_PACK_WPG", 1, 4, 4);          /* waves per workgroup of the writer */
     o->pack_stream = env_int("LC3PLUS_ENC_PACK_STREAM", 0, 1, -1);   /* 1 = the writers of consecutive calls on two side streams (deployment switch, see enc_launch) */
     o->resample48 = env_int("LC3PLUS_ENC_RESAMPLE48", 0, 1, 1);      /* 0 = the two-outputs-per-lane resampler for 48 kHz / 10 ms too */
+    o->resample96 = env_int("LC3PLUS_ENC_RESAMPLE96", 0, 2, 1);      /* the four-outputs-per-lane resampler for 96 kHz: 0 never, 1 standard kernel layout (2.5 ms frames), 2 every frame length */
     /* frames of this size and more: tail + writer a frame per wave (lc3_enc_tailw_kernel).  Off (0) by default - measured, Mframes/s: c96 (320-byte frames) 32.5 without,
      * 27.3 with; c5 (20 ... 400 bytes) 86.5 without, 68.6 / 73.6 / 78.4 from 120 / 200 / 320 bytes: the wave-parallel writer shortens the longest wave of the call but
      * costs several times the instructions per frame, and the call is bound by instructions, not by that latency. */
@@ -2968,7 +2969,7 @@ static void read_opts(lc3hip_opts* o)
 }
 struct lc3hip_ctx {
     lc3hip_opts opt;
-    int device, ncs, n_streams, channels, N, big, state_words, rs48;
+    int device, ncs, n_streams, channels, N, big, state_words, rs48, rs96;
     lc3d_plan* d_plan; lc3d_chan* d_chans; float* d_state;
     void* d_pcm; size_t pcm_cap; uint8_t* d_out; size_t out_cap;
     lc3d_trace* d_trace; size_t trace_cap;
@@ -3028,6 +3029,10 @@ extern "C" int lc3hip_create(void** out_ctx, const lc3d_plan* plan, int n_stream
     c->rs48 = plan->N == 480 && plan->rs_stride == 4 && plan->n12 == 128 && plan->rs_mem_in_len == 60;      /* lc3_enc_resample48_kernel */
     read_opts(&c->opt);
     if (!c->opt.resample48) c->rs48 = 0;
+    /* lc3_enc_resample96_kernel_n*: 96 kHz.  By default for the standard kernel layout only (2.5 ms frames): c4 125.0 -> 137.0 Mframes/s; beside the large-layout kernels its
+     * 256 registers per wave cost more than its shorter run gives (c96 36.6 -> 33.4) */
+    c->rs96 = c->opt.resample96 && plan->rs_stride == 2 && plan->rs_mem_in_len == 120 && (plan->N == 960 || plan->N == 480 || plan->N == 240) && plan->n12 * 15 == plan->N * 2
+              && (!c->big || c->opt.resample96 == 2);
     c->fused = c->opt.fused;
     c->state_words = LC3D_STATE_WORDS(c->big ? LC3D_MEMCAP_BIG : LC3D_MEMCAP_STD);
     HIPCHK_OR(hipMalloc((void**)&c->d_plan, sizeof(lc3d_plan)), lc3hip_destroy(c));
@@ -3095,6 +3100,11 @@ static void launch_resample(lc3hip_ctx* c, hipStream_t st, const void* dpcm, int
     const unsigned pruns = (unsigned)((hn + PRE_FPW - 1) / PRE_FPW);
     if (c->rs48 && bitdepth == 16 && (((size_t)dpcm) & 15) == 0)
         hipLaunchKernelGGL(lc3_enc_resample48_kernel, dim3((unsigned)c->ncs * pruns), dim3(WAVE), 0, st, c->d_plan, (const int16_t*)dpcm, c->channels, mc, n_frames, hb, hn, c->ncs, dy12, xprev, xprev_stride);
+    else if (c->rs96 && bitdepth == 16 && (((size_t)dpcm) & 15) == 0) {
+        auto k = c->N == 960 ? lc3_enc_resample96_kernel_n960 : c->N == 480 ? lc3_enc_resample96_kernel_n480 : lc3_enc_resample96_kernel_n240;
+        const int fpb = (1920 / c->N) * PRE96_ITERS;                       /* frames per workgroup: PRE96_ITERS steps of 1 920 samples */
+        hipLaunchKernelGGL(k, dim3((unsigned)c->ncs * (unsigned)((hn + fpb - 1) / fpb)), dim3(WAVE), 0, st, c->d_plan, (const int16_t*)dpcm, c->channels, mc, n_frames, hb, hn, c->ncs, dy12, xprev, xprev_stride);
+    }
     else
         hipLaunchKernelGGL(lc3_enc_resample_kernel, dim3((unsigned)c->ncs * pruns), dim3(WAVE), 0, st, c->d_plan, c->d_state, c->state_words, mc, dpcm, bitdepth, n_frames, hb, hn, c->ncs, dy12, xprev, xprev_stride);
 }

@@ -832,6 +832,37 @@ def test_odd_stream_counts_and_unaligned_pcm_on_the_pipelined_path(B, T, off):
         d.free()
 
 
+@pytest.mark.parametrize("level", [0, 1, 2])
+def test_resampler_for_96_khz_at_every_switch_level(level):
+    """lc3_enc_resample96_kernel_n240 / _n480 / _n960 (four outputs per lane, 1 920 samples = 8 / 4 / 2 frames per step): LC3PLUS_ENC_RESAMPLE96 = 0 (never),
+    1 (the default: 2.5 ms frames only) and 2 (every frame length) give the oracle's bytes at all three frame lengths, mono and stereo, with call lengths
+    that leave a step and a workgroup partly filled (11 + 8 + 1 frames: 32 / 16 / 8 frames per workgroup), state running on from call to call."""
+    import subprocess, sys, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import sys, numpy as np
+        sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import audio_codec_amd
+        from lc3_harness import synth_pcm
+        from test_gpu_parity import _oracle_batch_ch
+        for ms, N, ch, rates in ((2.5, 240, 1, [256000, 320000, 672000]), (2.5, 240, 2, [512000, 640000]), (5.0, 480, 1, [256000, 400000]), (10.0, 960, 1, [149600, 256000]), (10.0, 960, 2, [512000])):
+            B, T, fs = 3 * len(rates), 20, 96000
+            br = [rates[i %% len(rates)] for i in range(B)]
+            pcm = synth_pcm(B * ch, T, N, fs, seed=77 + N + ch).reshape(B, ch, T, N).transpose(0, 2, 1, 3).copy()      # [B, T, ch, N]
+            b = audio_codec_amd.Batch(B, fs, ch, ms, 1, br, device=0)
+            x = pcm if ch > 1 else pcm[:, :, 0]
+            got = np.concatenate([b.encode(x[:, :11]), b.encode(x[:, 11:19]), b.encode(x[:, 19:])], axis=1)
+            want = _oracle_batch_ch(pcm, fs, ms, 1, ch, br, b.stride)
+            nb = [b.num_bytes(i) for i in range(B)]
+            bad = [(i, t) for i in range(B) for t in range(T) if (got[i, t, :nb[i]] != want[i, t, :nb[i]]).any()]
+            assert not bad, (ms, N, ch, bad[:6])
+        print("ok")
+    """ % (root, os.path.join(root, "tests")))
+    env = dict(os.environ, LC3PLUS_ENC_RESAMPLE96=str(level))
+    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-2000:]
+
+
 @pytest.mark.parametrize("env", ["LC3PLUS_ENC_FRONT4=0", "LC3PLUS_ENC_PITCH2=0", "LC3PLUS_ENC_RATE_STREAM=1", "LC3PLUS_ENC_PACK_WPG=1", "LC3PLUS_DEC_IMDCT4=0",
                                  # round 4's switches: each alternative is byte-identical to the default
                                  "LC3PLUS_ENC_RESAMPLE48=0", "LC3PLUS_ENC_PACK_W5=1", "LC3PLUS_ENC_PACK_SPLIT=1", "LC3PLUS_ENC_FUSE_VQ=1", "LC3PLUS_ENC_RATE_ON=0",
