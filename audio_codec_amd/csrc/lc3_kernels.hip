@@ -3024,7 +3024,7 @@ extern "C" int lc3hip_create(void** out_ctx, const lc3d_plan* plan, int n_stream
     c->n_streams = n_streams; c->channels = plan->channels; c->ncs = n_streams * plan->channels; c->N = plan->N;
     c->big = LC3D_LAYOUT_BIG(plan->N, plan->la);
     c->hr = plan->hrmode; c->ylen = plan->ylen; c->la = plan->la; c->len12 = plan->len12;
-    c->fm_frames = (!c->big && plan->pfa_nst >= 2 && plan->pfa_rad[0] <= 8 && plan->pfa_rad[1] <= 8 && (plan->pfa_nst < 3 || plan->pfa_rad[2] <= 8) && plan->N <= 240) ? (plan->N > 120 ? 4 : 8) : 0;      /* lc3_enc_frontm_kernel */
+    c->fm_frames = (!c->big && plan->pfa_nst >= 2 && plan->pfa_rad[0] <= 8 && plan->pfa_rad[1] <= 8 && (plan->pfa_nst < 3 || plan->pfa_rad[2] <= 8) && plan->N <= 240) ? (plan->N > 120 ? FM_F240 : 8) : 0;      /* lc3_enc_frontm_kernel */
     c->srow = LC3D_SROW(plan->ylen);
     c->rs48 = plan->N == 480 && plan->rs_stride == 4 && plan->n12 == 128 && plan->rs_mem_in_len == 60;      /* lc3_enc_resample48_kernel */
     read_opts(&c->opt);
